@@ -1,0 +1,82 @@
+"""ctypes binding of libhades252.so -- the same C ABI a Rust `extern "C"` block would bind
+(include/hades252.h).  There is no fallback: if the library is missing this module raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_size_t, c_uint64, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhades252.so")
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_HIP = -2
+ERR_NOT_CANONICAL = -3
+ERR_NO_DEVICE = -4
+ERR_SCRATCH = -5
+
+KERNEL_DEFAULT = 0
+KERNEL_LITERAL = 1
+KERNEL_FAST = 2
+
+# every symbol include/hades252.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "hades252_rounds": (c_int, []),
+    "hades252_device_count": (c_int, []),
+    "hades252_strerror": (c_char_p, [c_int]),
+    "hades252_last_hip_error": (c_int, []),
+    "hades252_version": (c_char_p, []),
+    "hades252_perm_batch": (c_int, [c_void_p, c_size_t]),
+    "hades252_perm_batch_bytes": (c_int, [c_void_p, c_size_t]),
+    "hades252_perm_batch_dev": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "hades252_perm_batch_dev_ex": (c_int, [c_void_p, c_size_t, c_void_p, c_int]),
+    "hades252_perm_batch_multi": (c_int, [c_void_p, c_size_t, c_int]),
+    "hades252_add_round_key_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
+    "hades252_quintic_s_box_dev": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "hades252_mul_matrix_dev": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "hades252_apply_full_round_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
+    "hades252_apply_partial_round_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
+    "hades252_from_bytes_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "hades252_to_bytes_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hades252_merkle4_level_dev": (c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_uint64), c_int, c_void_p]),
+    "hades252_merkle4_scratch_bytes": (c_size_t, [c_size_t]),
+    "hades252_merkle4_root_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, POINTER(c_uint64), c_int,
+                                          c_void_p, c_void_p]),
+    "hades252_gen_b_dev": (c_int, [c_void_p, c_uint64, c_size_t, c_uint64, c_void_p]),
+    "hades252_gen_a_dev": (c_int, [c_void_p, c_uint64, c_size_t, c_void_p]),
+    "hades252_digest_dev": (c_int, [c_void_p, c_uint64, c_size_t, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class HadesError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        self.code = code
+        msg = lib().hades252_strerror(code).decode()
+        if code == ERR_HIP:
+            msg += " [hipError_t %d]" % lib().hades252_last_hip_error()
+        super().__init__("%s: %s (%d)" % (where, msg, code))
+
+
+def lib() -> ctypes.CDLL:
+    """Load libhades252.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libhades252.so is missing (%s). Build it with `python -m hades252_amd.build`; "
+                "hades252_amd has no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)           # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code: int, where: str) -> None:
+    if code != OK:
+        raise HadesError(code, where)

@@ -1,0 +1,535 @@
+// hades252.hip -- kernels + C ABI of libhades252 (gfx950 only).  See include/hades252.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <thread>
+#include <vector>
+
+#include "../../include/hades252.h"
+#include "fr32.cuh"
+#include "hades_constants.inc"
+#include "hades_literal.cuh"
+#include "staging.cuh"
+#ifdef HADES_HAVE_FAST
+#include "hades_fast.cuh"
+#endif
+
+using namespace hades;
+
+// ------------------------------------------------------------------------------------------
+// constant tables (code-object globals: one copy per device, loaded with the module)
+// ------------------------------------------------------------------------------------------
+__device__ const uint32_t d_ark_mont[HADES_N_ARK_USED][8] = HADES_ARK_MONT_INIT;
+__device__ const uint32_t d_mds_mont[25][8] = HADES_MDS_MONT_INIT;
+// R^2 mod p (from_raw / from_bytes multiplier) and 1 (to_bytes multiplier), 8 x u32
+__device__ const uint32_t d_r2[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu,
+                                     0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ uint8_t *wave_slab(uint8_t *lds) {
+    return lds + (threadIdx.x / kWave) * lds_wave_bytes(NW);
+}
+
+enum Op { OP_PERM = 0, OP_ARK, OP_MDS, OP_FULL, OP_PARTIAL };
+
+template <int OP>
+__global__ void __launch_bounds__(kBlock) k_states_literal(uint8_t *__restrict__ states, size_t n, int round) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<5>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr st[5];
+    wave_load_records<5>(states, rec0, n, slab, st);
+    LiteralView V{d_ark_mont, d_mds_mont};
+    if constexpr (OP == OP_PERM) lit_perm(V, st);
+    if constexpr (OP == OP_ARK) lit_add_round_key(V, round, st);
+    if constexpr (OP == OP_MDS) lit_mul_matrix(V, st);
+    if constexpr (OP == OP_FULL) lit_full_round(V, round, st);
+    if constexpr (OP == OP_PARTIAL) lit_partial_round(V, round, st);
+    wave_store_records<5>(states, rec0, n, slab, st);
+}
+
+__global__ void __launch_bounds__(kBlock) k_sbox(uint8_t *__restrict__ scalars, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<1>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr st[1];
+    wave_load_records<1>(scalars, rec0, n, slab, st);
+    st[0] = lit_quintic_s_box(st[0]);
+    wave_store_records<1>(scalars, rec0, n, slab, st);
+}
+
+// canonical bytes <-> Montgomery limbs (32 B each way, one scalar per lane)
+__global__ void __launch_bounds__(kBlock) k_from_bytes(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                       size_t n, int *bad_count) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<1>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr st[1];
+    wave_load_records<1>(in, rec0, n, slab, st);
+    bool ok = fr_is_canonical(st[0]);
+    Fr r2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r2.l[i] = d_r2[i];
+    Fr m = fr_mul(st[0], r2);
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) m.l[i] = 0;
+        size_t rec = rec0 + (threadIdx.x & (kWave - 1));
+        if (bad_count != nullptr && rec < n) atomicAdd(bad_count, 1);
+    }
+    st[0] = m;
+    wave_store_records<1>(out, rec0, n, slab, st);
+}
+
+__global__ void __launch_bounds__(kBlock) k_to_bytes(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<1>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr st[1];
+    wave_load_records<1>(in, rec0, n, slab, st);
+    Fr one;
+#pragma unroll
+    for (int i = 0; i < 8; i++) one.l[i] = (i == 0);
+    st[0] = fr_mul(st[0], one);              // a * 1 / R = canonical value
+    wave_store_records<1>(out, rec0, n, slab, st);
+}
+
+// Merkle level: lane i hashes children[4i..4i+4) -> parents[i]
+__global__ void __launch_bounds__(kBlock) k_merkle4_level_literal(const uint8_t *__restrict__ children,
+                                                                  uint8_t *__restrict__ parents, size_t n_parents,
+                                                                  Fr tag, int out_idx) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<4>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr ch[4];
+    wave_load_records<4>(children, rec0, n_parents, slab, ch);
+    Fr st[5] = {tag, ch[0], ch[1], ch[2], ch[3]};
+    LiteralView V{d_ark_mont, d_mds_mont};
+    lit_perm(V, st);
+    Fr out[1];
+    out[0] = st[0];
+#pragma unroll
+    for (int w = 1; w < 5; w++)
+        if (out_idx == w) out[0] = st[w];
+    wave_store_records<1>(parents, rec0, n_parents, slab, out);
+}
+
+__device__ __forceinline__ uint64_t splitmix_limb(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// one u64 limb per thread: perfectly coalesced 8-byte stores
+__global__ void __launch_bounds__(kBlock) k_gen_b(uint64_t *__restrict__ out, uint64_t first_elem, size_t n_limbs,
+                                                  uint64_t seed) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * kBlock;
+    for (; i < n_limbs; i += stride) {
+        uint64_t z = splitmix_limb(seed, 4 * first_elem + i);
+        if ((i & 3) == 3) z &= 0x3fffffffffffffffull;
+        out[i] = z;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_gen_a(uint8_t *__restrict__ out, uint64_t first_elem, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<1>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    uint64_t v = first_elem + rec0 + (threadIdx.x & (kWave - 1));
+    Fr a;
+#pragma unroll
+    for (int i = 0; i < 8; i++) a.l[i] = 0;
+    a.l[0] = (uint32_t)v;
+    a.l[1] = (uint32_t)(v >> 32);
+    Fr r2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r2.l[i] = d_r2[i];
+    Fr st[1];
+    st[0] = fr_mul(a, r2);
+    wave_store_records<1>(out, rec0, n, slab, st);
+}
+
+__device__ __forceinline__ uint64_t digest_mix(uint64_t w, uint64_t idx) {
+    uint64_t z = w ^ (idx * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull);
+    z = (z ^ (z >> 32)) * 0xD6E8FEB86659FD93ull;
+    z = (z ^ (z >> 29)) * 0xBF58476D1CE4E5B9ull;
+    return z ^ (z >> 32);
+}
+
+__global__ void __launch_bounds__(kBlock) k_digest(const uint64_t *__restrict__ words, uint64_t first_index,
+                                                   size_t n, unsigned long long *out4) {
+    // thread t always sees word indices == t (mod 4) because the stride is a multiple of 4
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * kBlock;
+    uint64_t acc = 0;
+    for (; i < n; i += stride) acc += digest_mix(words[i], first_index + i);
+    __shared__ unsigned long long part[4];
+    if (threadIdx.x < 4) part[threadIdx.x] = 0;
+    __syncthreads();
+    // lanes with equal (lane & 3) reduce together
+    for (int off = 32; off >= 4; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & (kWave - 1)) < 4) atomicAdd(&part[threadIdx.x & 3], (unsigned long long)acc);
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(&out4[(first_index + threadIdx.x) & 3], part[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static thread_local int tl_last_hip_error = 0;
+
+#define HIP_TRY(expr)                                \
+    do {                                             \
+        hipError_t e_ = (expr);                      \
+        if (e_ != hipSuccess) {                      \
+            tl_last_hip_error = (int)e_;             \
+            (void)hipGetLastError();                 \
+            return HADES252_ERR_HIP;                 \
+        }                                            \
+    } while (0)
+
+static inline unsigned blocks_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+static inline size_t lds_for(int nw) { return (size_t)kWavesPerBlock * lds_wave_bytes(nw); }
+static constexpr size_t kMaxLaunchRecords = (size_t)1 << 30;   // grid.x * 256 per launch
+
+static int check_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        tl_last_hip_error = (int)e;
+        (void)hipGetLastError();
+        return HADES252_ERR_NO_DEVICE;
+    }
+    return n > 0 ? HADES252_OK : HADES252_ERR_NO_DEVICE;
+}
+
+extern "C" {
+
+int hades252_rounds(void) { return HADES252_TOTAL_FULL_ROUNDS + HADES252_PARTIAL_ROUNDS; }
+
+int hades252_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char *hades252_strerror(int code) {
+    switch (code) {
+        case HADES252_OK: return "ok";
+        case HADES252_ERR_INVALID_ARG: return "invalid argument";
+        case HADES252_ERR_HIP: return "HIP runtime error (see hades252_last_hip_error)";
+        case HADES252_ERR_NOT_CANONICAL: return "input scalar is not canonical (>= p)";
+        case HADES252_ERR_NO_DEVICE: return "no HIP device available";
+        case HADES252_ERR_SCRATCH: return "scratch buffer too small";
+        default: return "unknown error";
+    }
+}
+
+int hades252_last_hip_error(void) { return tl_last_hip_error; }
+
+const char *hades252_version(void) { return "hades252-amd 0.1.0 (gfx950)"; }
+
+// ---- perm ---------------------------------------------------------------------------------
+int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int kernel) {
+    if (n_perms == 0) return HADES252_OK;
+    if (d_states == nullptr) return HADES252_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t *p = (uint8_t *)d_states;
+#ifdef HADES_HAVE_FAST
+    if (kernel == HADES252_KERNEL_DEFAULT) kernel = HADES252_KERNEL_FAST;
+#else
+    if (kernel == HADES252_KERNEL_DEFAULT) kernel = HADES252_KERNEL_LITERAL;
+#endif
+    for (size_t off = 0; off < n_perms; off += kMaxLaunchRecords) {
+        size_t n = n_perms - off < kMaxLaunchRecords ? n_perms - off : kMaxLaunchRecords;
+        if (kernel == HADES252_KERNEL_LITERAL) {
+            hipLaunchKernelGGL(k_states_literal<OP_PERM>, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s,
+                               p + off * 160, n, 0);
+#ifdef HADES_HAVE_FAST
+        } else if (kernel == HADES252_KERNEL_FAST) {
+            int rc = launch_perm_fast(p + off * 160, n, s);
+            if (rc != HADES252_OK) return rc;
+#endif
+        } else {
+            return HADES252_ERR_INVALID_ARG;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return HADES252_OK;
+}
+
+int hades252_perm_batch_dev(void *d_states, size_t n_perms, void *stream) {
+    return hades252_perm_batch_dev_ex(d_states, n_perms, stream, HADES252_KERNEL_DEFAULT);
+}
+
+// Host batch on the current device: chunked, double-buffered H2D / kernel / D2H on two streams.
+static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, bool bytes_format) {
+    if (n_perms == 0) return HADES252_OK;
+    if (states == nullptr) return HADES252_ERR_INVALID_ARG;
+    int rc = check_device();
+    if (rc != HADES252_OK) return rc;
+    const size_t kChunk = (size_t)1 << 18;                // 40 MiB of states per chunk
+    const size_t chunk = n_perms < kChunk ? n_perms : kChunk;
+    void *dbuf[2] = {nullptr, nullptr};
+    hipStream_t st[2] = {nullptr, nullptr};
+    int *d_bad = nullptr;
+    int result = HADES252_OK;
+    auto cleanup = [&]() {
+        for (int i = 0; i < 2; i++) {
+            if (st[i]) (void)hipStreamDestroy(st[i]);
+            if (dbuf[i]) (void)hipFree(dbuf[i]);
+        }
+        if (d_bad) (void)hipFree(d_bad);
+    };
+#define TRY_CLEAN(expr)                              \
+    do {                                             \
+        hipError_t e_ = (expr);                      \
+        if (e_ != hipSuccess) {                      \
+            tl_last_hip_error = (int)e_;             \
+            (void)hipGetLastError();                 \
+            cleanup();                               \
+            return HADES252_ERR_HIP;                 \
+        }                                            \
+    } while (0)
+    const int nbuf = n_perms > chunk ? 2 : 1;
+    for (int i = 0; i < nbuf; i++) {
+        TRY_CLEAN(hipMalloc(&dbuf[i], chunk * 160));
+        TRY_CLEAN(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+    }
+    if (bytes_format) {
+        TRY_CLEAN(hipMalloc((void **)&d_bad, sizeof(int)));
+        TRY_CLEAN(hipMemset(d_bad, 0, sizeof(int)));
+    }
+    uint8_t *h = (uint8_t *)states;
+    int k = 0;
+    for (size_t off = 0; off < n_perms; off += chunk, k ^= (nbuf - 1)) {
+        size_t n = n_perms - off < chunk ? n_perms - off : chunk;
+        TRY_CLEAN(hipMemcpyAsync(dbuf[k], h + off * 160, n * 160, hipMemcpyHostToDevice, st[k]));
+        if (bytes_format) {
+            rc = hades252_from_bytes_dev(dbuf[k], dbuf[k], n * 5, d_bad, st[k]);
+            if (rc == HADES252_OK) rc = hades252_perm_batch_dev(dbuf[k], n, st[k]);
+            if (rc == HADES252_OK) rc = hades252_to_bytes_dev(dbuf[k], dbuf[k], n * 5, st[k]);
+        } else {
+            rc = hades252_perm_batch_dev(dbuf[k], n, st[k]);
+        }
+        if (rc != HADES252_OK) {
+            for (int i = 0; i < nbuf; i++) (void)hipStreamSynchronize(st[i]);
+            cleanup();
+            return rc;
+        }
+        if (bytes_format) {
+            // results of a batch with a non-canonical input are not written back
+            int bad = 0;
+            TRY_CLEAN(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st[k]));
+            TRY_CLEAN(hipStreamSynchronize(st[k]));
+            if (bad != 0) {
+                result = HADES252_ERR_NOT_CANONICAL;
+                break;
+            }
+        }
+        TRY_CLEAN(hipMemcpyAsync(h + off * 160, dbuf[k], n * 160, hipMemcpyDeviceToHost, st[k]));
+    }
+    for (int i = 0; i < nbuf; i++) TRY_CLEAN(hipStreamSynchronize(st[i]));
+#undef TRY_CLEAN
+    cleanup();
+    return result;
+}
+
+int hades252_perm_batch(uint64_t *states, size_t n_perms) {
+    return perm_batch_host_on_current_device(states, n_perms, false);
+}
+
+int hades252_perm_batch_bytes(uint8_t *states, size_t n_perms) {
+    return perm_batch_host_on_current_device((uint64_t *)states, n_perms, true);
+}
+
+int hades252_perm_batch_multi(uint64_t *states, size_t n_perms, int n_devices) {
+    if (n_perms == 0) return HADES252_OK;
+    if (states == nullptr) return HADES252_ERR_INVALID_ARG;
+    int avail = hades252_device_count();
+    if (avail <= 0) return HADES252_ERR_NO_DEVICE;
+    if (n_devices <= 0) n_devices = avail;
+    if (n_devices > avail) return HADES252_ERR_INVALID_ARG;
+    if ((size_t)n_devices > n_perms) n_devices = (int)n_perms;
+    std::vector<int> rcs(n_devices, HADES252_OK);
+    std::vector<int> hip_errs(n_devices, 0);
+    std::vector<std::thread> threads;
+    for (int g = 0; g < n_devices; g++) {
+        threads.emplace_back([&, g]() {
+            size_t b = n_perms * (size_t)g / n_devices, e = n_perms * (size_t)(g + 1) / n_devices;
+            hipError_t err = hipSetDevice(g);
+            if (err != hipSuccess) {
+                rcs[g] = HADES252_ERR_HIP;
+                hip_errs[g] = (int)err;
+                return;
+            }
+            rcs[g] = perm_batch_host_on_current_device(states + 20 * b, e - b, false);
+            hip_errs[g] = tl_last_hip_error;
+        });
+    }
+    for (auto &t : threads) t.join();
+    for (int g = 0; g < n_devices; g++)
+        if (rcs[g] != HADES252_OK) {
+            tl_last_hip_error = hip_errs[g];
+            return rcs[g];
+        }
+    return HADES252_OK;
+}
+
+// ---- per-op --------------------------------------------------------------------------------
+#define STATES_OP(NAME, OPV, NEEDS_ROUND)                                                              \
+    int NAME(void *d_states, size_t n_states, int round, void *stream) {                               \
+        if (n_states == 0) return HADES252_OK;                                                         \
+        if (d_states == nullptr || n_states > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;      \
+        if (NEEDS_ROUND && (round < 0 || round >= hades252_rounds())) return HADES252_ERR_INVALID_ARG; \
+        hipLaunchKernelGGL(k_states_literal<OPV>, dim3(blocks_for(n_states)), dim3(kBlock), lds_for(5), \
+                           (hipStream_t)stream, (uint8_t *)d_states, n_states, round);                 \
+        HIP_TRY(hipGetLastError());                                                                    \
+        return HADES252_OK;                                                                            \
+    }
+STATES_OP(hades252_add_round_key_dev, OP_ARK, true)
+STATES_OP(hades252_apply_full_round_dev, OP_FULL, true)
+STATES_OP(hades252_apply_partial_round_dev, OP_PARTIAL, true)
+#undef STATES_OP
+
+int hades252_mul_matrix_dev(void *d_states, size_t n_states, void *stream) {
+    if (n_states == 0) return HADES252_OK;
+    if (d_states == nullptr || n_states > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_states_literal<OP_MDS>, dim3(blocks_for(n_states)), dim3(kBlock), lds_for(5),
+                       (hipStream_t)stream, (uint8_t *)d_states, n_states, 0);
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
+int hades252_quintic_s_box_dev(void *d_scalars, size_t n_scalars, void *stream) {
+    if (n_scalars == 0) return HADES252_OK;
+    if (d_scalars == nullptr || n_scalars > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_sbox, dim3(blocks_for(n_scalars)), dim3(kBlock), lds_for(1), (hipStream_t)stream,
+                       (uint8_t *)d_scalars, n_scalars);
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
+// ---- wire format ----------------------------------------------------------------------------
+int hades252_from_bytes_dev(const void *d_bytes, void *d_limbs, size_t n_scalars, int *d_bad_count, void *stream) {
+    if (n_scalars == 0) return HADES252_OK;
+    if (d_bytes == nullptr || d_limbs == nullptr || n_scalars > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_from_bytes, dim3(blocks_for(n_scalars)), dim3(kBlock), lds_for(1), (hipStream_t)stream,
+                       (const uint8_t *)d_bytes, (uint8_t *)d_limbs, n_scalars, d_bad_count);
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
+int hades252_to_bytes_dev(const void *d_limbs, void *d_bytes, size_t n_scalars, void *stream) {
+    if (n_scalars == 0) return HADES252_OK;
+    if (d_bytes == nullptr || d_limbs == nullptr || n_scalars > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_to_bytes, dim3(blocks_for(n_scalars)), dim3(kBlock), lds_for(1), (hipStream_t)stream,
+                       (const uint8_t *)d_limbs, (uint8_t *)d_bytes, n_scalars);
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
+// ---- Merkle ----------------------------------------------------------------------------------
+int hades252_merkle4_level_dev(const void *d_children, void *d_parents, size_t n_parents, const uint64_t tag_mont[4],
+                               int out_idx, void *stream) {
+    if (n_parents == 0) return HADES252_OK;
+    if (d_children == nullptr || d_parents == nullptr || tag_mont == nullptr || out_idx < 0 || out_idx >= 5 ||
+        n_parents > kMaxLaunchRecords)
+        return HADES252_ERR_INVALID_ARG;
+    Fr tag;
+    for (int k = 0; k < 4; k++) {
+        tag.l[2 * k] = (uint32_t)tag_mont[k];
+        tag.l[2 * k + 1] = (uint32_t)(tag_mont[k] >> 32);
+    }
+#ifdef HADES_HAVE_FAST
+    int rc = launch_merkle4_level_fast((const uint8_t *)d_children, (uint8_t *)d_parents, n_parents, tag, out_idx,
+                                       (hipStream_t)stream);
+    if (rc != HADES252_OK) return rc;
+#else
+    hipLaunchKernelGGL(k_merkle4_level_literal, dim3(blocks_for(n_parents)), dim3(kBlock), lds_for(4),
+                       (hipStream_t)stream, (const uint8_t *)d_children, (uint8_t *)d_parents, n_parents, tag, out_idx);
+#endif
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
+static bool is_pow4(size_t n) { return n >= 4 && (n & (n - 1)) == 0 && (__builtin_ctzll(n) % 2) == 0; }
+
+size_t hades252_merkle4_scratch_bytes(size_t n_leaves) {
+    // two ping-pong buffers: level 1 (n/4 nodes) and level 2 (n/16 nodes)
+    if (!is_pow4(n_leaves)) return 0;
+    size_t a = (n_leaves / 4) * 32, b = (n_leaves >= 16 ? n_leaves / 16 : 1) * 32;
+    return a + b;
+}
+
+int hades252_merkle4_root_dev(const void *d_leaves, size_t n_leaves, void *d_scratch, size_t scratch_bytes,
+                              const uint64_t tag_mont[4], int out_idx, void *d_root, void *stream) {
+    if (d_leaves == nullptr || d_root == nullptr || tag_mont == nullptr || !is_pow4(n_leaves))
+        return HADES252_ERR_INVALID_ARG;
+    if (scratch_bytes < hades252_merkle4_scratch_bytes(n_leaves) || (d_scratch == nullptr && n_leaves > 4))
+        return HADES252_ERR_SCRATCH;
+    uint8_t *buf_a = (uint8_t *)d_scratch;
+    uint8_t *buf_b = buf_a + (n_leaves / 4) * 32;
+    const uint8_t *src = (const uint8_t *)d_leaves;
+    size_t n = n_leaves;
+    bool to_a = true;
+    while (n > 1) {
+        size_t parents = n / 4;
+        uint8_t *dst = parents == 1 ? (uint8_t *)d_root : (to_a ? buf_a : buf_b);
+        int rc = hades252_merkle4_level_dev(src, dst, parents, tag_mont, out_idx, stream);
+        if (rc != HADES252_OK) return rc;
+        src = dst;
+        n = parents;
+        to_a = !to_a;
+    }
+    return HADES252_OK;
+}
+
+// ---- synthetic / digest ------------------------------------------------------------------------
+int hades252_gen_b_dev(void *d_scalars, uint64_t first_elem, size_t n_elems, uint64_t seed, void *stream) {
+    if (n_elems == 0) return HADES252_OK;
+    if (d_scalars == nullptr) return HADES252_ERR_INVALID_ARG;
+    size_t n_limbs = n_elems * 4;
+    size_t want = (n_limbs + kBlock - 1) / kBlock;
+    unsigned grid = (unsigned)(want < 65536 ? want : 65536);
+    hipLaunchKernelGGL(k_gen_b, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, (uint64_t *)d_scalars, first_elem,
+                       n_limbs, seed);
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
+int hades252_gen_a_dev(void *d_scalars, uint64_t first_elem, size_t n_elems, void *stream) {
+    if (n_elems == 0) return HADES252_OK;
+    if (d_scalars == nullptr || n_elems > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_gen_a, dim3(blocks_for(n_elems)), dim3(kBlock), lds_for(1), (hipStream_t)stream,
+                       (uint8_t *)d_scalars, first_elem, n_elems);
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
+int hades252_digest_dev(const void *d_words, uint64_t first_index, size_t n_u64, void *d_out4, void *stream) {
+    if (d_out4 == nullptr || (d_words == nullptr && n_u64 > 0)) return HADES252_ERR_INVALID_ARG;
+    HIP_TRY(hipMemsetAsync(d_out4, 0, 32, (hipStream_t)stream));
+    if (n_u64 == 0) return HADES252_OK;
+    size_t want = (n_u64 + kBlock - 1) / kBlock;
+    unsigned grid = (unsigned)(want < 4096 ? want : 4096);
+    hipLaunchKernelGGL(k_digest, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, (const uint64_t *)d_words,
+                       first_index, n_u64, (unsigned long long *)d_out4);
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
+}  // extern "C"

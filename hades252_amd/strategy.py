@@ -1,0 +1,301 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+The reference exposes ``pub trait Strategy<T>`` (src/strategies.rs:31-163) and the implementor
+``ScalarStrategy`` (src/strategies/scalar.rs:11-50).  This module keeps the same names, argument
+meaning and error behaviour, batched: wherever the reference takes ``&mut [BlsScalar]`` of
+exactly ``WIDTH`` words, these methods take a buffer holding any whole number of states
+(AoS, 160 bytes each, in-memory ``BlsScalar`` = 4 x u64 LE Montgomery limbs) and apply the
+operation to every state, in place, on the GPU through the C ABI of ``include/hades252.h``.
+
+Buffers
+  * ``torch.Tensor`` on a ``cuda`` device (any integer dtype, contiguous): device path,
+    asynchronous on the current torch stream -- zero-copy.
+  * ``numpy.ndarray`` of dtype uint64 (C-contiguous): host path, synchronous, the library moves
+    the data (``hades252_perm_batch``); only ``perm`` supports it.
+
+There is no CPU implementation behind these methods: if ``libhades252.so`` is not built or no
+GPU is usable they raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Iterator
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+WIDTH = 5
+TOTAL_FULL_ROUNDS = 8
+PARTIAL_ROUNDS = 59
+STATE_BYTES = WIDTH * 32
+N_ROUND_CONSTANTS = 960          # src/round_constants.rs:18 (335 are ever consumed)
+
+
+class RoundConstantsIter:
+    """``ROUND_CONSTANTS.iter()`` (src/strategies.rs:141): a cursor into the constant table.
+    The table itself lives in device memory; the cursor is an index."""
+
+    def __init__(self, pos: int = 0):
+        self.pos = pos
+
+    def __iter__(self) -> Iterator[int]:
+        return self
+
+    def __next__(self) -> int:
+        if self.pos >= N_ROUND_CONSTANTS:
+            raise StopIteration
+        self.pos += 1
+        return self.pos - 1
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _dev_buffer(x, unit_bytes: int, what: str):
+    """-> (data_ptr, n_units, torch device) of a contiguous CUDA tensor."""
+    import torch
+    if not isinstance(x, torch.Tensor) or x.device.type != "cuda":
+        raise TypeError("%s: expected a CUDA torch.Tensor" % what)
+    if not x.is_contiguous():
+        raise ValueError("%s: tensor must be contiguous" % what)
+    nbytes = x.numel() * x.element_size()
+    # same failure the reference has for a slice whose length is not WIDTH
+    # (copy_from_slice length panic, src/strategies/scalar.rs:48)
+    if nbytes % unit_bytes != 0:
+        raise ValueError("%s: buffer of %d bytes is not a whole number of %d-byte units"
+                         % (what, nbytes, unit_bytes))
+    if x.data_ptr() % 16 != 0:
+        raise ValueError("%s: buffer must be 16-byte aligned" % what)
+    return x.data_ptr(), nbytes // unit_bytes, x.device
+
+
+def _stream_ptr(device) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class Strategy:
+    """Mirror of ``pub trait Strategy<T: Clone + Copy>`` (src/strategies.rs:31)."""
+
+    @staticmethod
+    def next_c(constants: RoundConstantsIter) -> int:
+        """src/strategies.rs:33-41 -- returns the index of the constant consumed."""
+        try:
+            return next(constants)
+        except StopIteration:
+            raise RuntimeError("Hades252 out of ARK constants") from None
+
+    # required methods of the trait (src/strategies.rs:50-65)
+    def add_round_key(self, constants: RoundConstantsIter, words) -> None:
+        raise NotImplementedError
+
+    def quintic_s_box(self, value) -> None:
+        raise NotImplementedError
+
+    def mul_matrix(self, constants: RoundConstantsIter, values) -> None:
+        raise NotImplementedError
+
+    # provided methods (src/strategies.rs:79-157)
+    def apply_partial_round(self, constants: RoundConstantsIter, words) -> None:
+        raise NotImplementedError
+
+    def apply_full_round(self, constants: RoundConstantsIter, words) -> None:
+        raise NotImplementedError
+
+    def perm(self, data) -> None:
+        raise NotImplementedError
+
+    @staticmethod
+    def rounds() -> int:
+        """src/strategies.rs:160-162."""
+        return TOTAL_FULL_ROUNDS + PARTIAL_ROUNDS
+
+
+class ScalarStrategy(Strategy):
+    """Batched GPU ``ScalarStrategy`` (src/strategies/scalar.rs:11-50).  Stateless, like the
+    reference's zero-sized struct; ``kernel`` selects one of the two bit-identical kernels."""
+
+    def __init__(self, kernel: int = _lib.KERNEL_DEFAULT):
+        self.kernel = kernel
+        _lib.lib()                       # fail loudly at construction if the library is missing
+
+    @classmethod
+    def new(cls) -> "ScalarStrategy":
+        """src/strategies/scalar.rs:17-19."""
+        return cls()
+
+    @staticmethod
+    def _round_of(constants: RoundConstantsIter, what: str) -> int:
+        if constants.pos % WIDTH != 0:
+            raise ValueError("%s: constant cursor %d is not at a round boundary" % (what, constants.pos))
+        rnd = constants.pos // WIDTH
+        if rnd >= Strategy.rounds():
+            # the device table holds the 335 constants `perm` consumes
+            raise RuntimeError("Hades252 out of ARK constants")
+        return rnd
+
+    def add_round_key(self, constants: RoundConstantsIter, words) -> None:
+        """src/strategies/scalar.rs:23-30: word w of every state += next_c()."""
+        import torch
+        ptr, n, dev = _dev_buffer(words, STATE_BYTES, "add_round_key")
+        rnd = self._round_of(constants, "add_round_key")
+        with torch.cuda.device(dev):
+            check(_lib.lib().hades252_add_round_key_dev(ptr, n, rnd, _stream_ptr(dev)), "add_round_key")
+        for _ in range(WIDTH):
+            self.next_c(constants)
+
+    def quintic_s_box(self, value) -> None:
+        """src/strategies/scalar.rs:32-34 on every 32-byte scalar of ``value``."""
+        import torch
+        ptr, n, dev = _dev_buffer(value, 32, "quintic_s_box")
+        with torch.cuda.device(dev):
+            check(_lib.lib().hades252_quintic_s_box_dev(ptr, n, _stream_ptr(dev)), "quintic_s_box")
+
+    def mul_matrix(self, constants: RoundConstantsIter, values) -> None:
+        """src/strategies/scalar.rs:36-49 (``_constants`` is unused there too)."""
+        import torch
+        ptr, n, dev = _dev_buffer(values, STATE_BYTES, "mul_matrix")
+        with torch.cuda.device(dev):
+            check(_lib.lib().hades252_mul_matrix_dev(ptr, n, _stream_ptr(dev)), "mul_matrix")
+
+    def apply_partial_round(self, constants: RoundConstantsIter, words) -> None:
+        """src/strategies.rs:79-93, fused in one launch."""
+        import torch
+        ptr, n, dev = _dev_buffer(words, STATE_BYTES, "apply_partial_round")
+        rnd = self._round_of(constants, "apply_partial_round")
+        with torch.cuda.device(dev):
+            check(_lib.lib().hades252_apply_partial_round_dev(ptr, n, rnd, _stream_ptr(dev)), "apply_partial_round")
+        for _ in range(WIDTH):
+            self.next_c(constants)
+
+    def apply_full_round(self, constants: RoundConstantsIter, words) -> None:
+        """src/strategies.rs:107-119, fused in one launch."""
+        import torch
+        ptr, n, dev = _dev_buffer(words, STATE_BYTES, "apply_full_round")
+        rnd = self._round_of(constants, "apply_full_round")
+        with torch.cuda.device(dev):
+            check(_lib.lib().hades252_apply_full_round_dev(ptr, n, rnd, _stream_ptr(dev)), "apply_full_round")
+        for _ in range(WIDTH):
+            self.next_c(constants)
+
+    def perm(self, data) -> None:
+        """src/strategies.rs:140-157 on every state of ``data``, in place."""
+        if isinstance(data, np.ndarray):
+            if data.dtype != np.uint64 or not data.flags["C_CONTIGUOUS"]:
+                raise TypeError("perm: host buffers must be C-contiguous numpy uint64")
+            if data.size % (WIDTH * 4) != 0:
+                raise ValueError("perm: %d limbs is not a whole number of %d-word states" % (data.size, WIDTH))
+            check(_lib.lib().hades252_perm_batch(data.ctypes.data_as(ctypes.c_void_p), data.size // (WIDTH * 4)),
+                  "perm")
+            return
+        import torch
+        ptr, n, dev = _dev_buffer(data, STATE_BYTES, "perm")
+        with torch.cuda.device(dev):
+            check(_lib.lib().hades252_perm_batch_dev_ex(ptr, n, _stream_ptr(dev), self.kernel), "perm")
+
+    def perm_stepwise(self, data) -> None:
+        """The provided ``perm`` body of the trait written out over the per-round entry points
+        (src/strategies.rs:140-157): 4 full, 59 partial, 4 full, one shared cursor."""
+        constants = RoundConstantsIter()
+        for _ in range(TOTAL_FULL_ROUNDS // 2):
+            self.apply_full_round(constants, data)
+        for _ in range(PARTIAL_ROUNDS):
+            self.apply_partial_round(constants, data)
+        for _ in range(TOTAL_FULL_ROUNDS // 2):
+            self.apply_full_round(constants, data)
+
+
+# ---- helpers around the strategy (wire format, Merkle, synthetic data) ----------------------
+def from_bytes(bytes_t, out_t=None):
+    """``BlsScalar::from_bytes`` on device: 32-byte canonical LE -> Montgomery limbs.
+    Raises ValueError if any input is >= p (the reference returns an error option)."""
+    import torch
+    ptr, n, dev = _dev_buffer(bytes_t, 32, "from_bytes")
+    out_t = torch.empty_like(bytes_t) if out_t is None else out_t
+    optr, n2, _ = _dev_buffer(out_t, 32, "from_bytes")
+    assert n2 == n
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_from_bytes_dev(ptr, optr, n, bad.data_ptr(), _stream_ptr(dev)), "from_bytes")
+    if int(bad.item()) != 0:
+        raise ValueError("from_bytes: %d scalar(s) not canonical (>= p)" % int(bad.item()))
+    return out_t
+
+
+def to_bytes(limbs_t, out_t=None):
+    """``BlsScalar::to_bytes`` on device."""
+    import torch
+    ptr, n, dev = _dev_buffer(limbs_t, 32, "to_bytes")
+    out_t = torch.empty_like(limbs_t) if out_t is None else out_t
+    optr, n2, _ = _dev_buffer(out_t, 32, "to_bytes")
+    assert n2 == n
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_to_bytes_dev(ptr, optr, n, _stream_ptr(dev)), "to_bytes")
+    return out_t
+
+
+def _tag_arr(tag_mont: int):
+    return (ctypes.c_uint64 * 4)(*[(tag_mont >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)])
+
+
+def merkle4_level(children_t, tag_mont: int, out_idx: int = 1):
+    """One arity-4 level: parent = perm([tag, c0, c1, c2, c3])[out_idx]."""
+    import torch
+    ptr, n, dev = _dev_buffer(children_t, 128, "merkle4_level")
+    parents = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_merkle4_level_dev(ptr, parents.data_ptr(), n, _tag_arr(tag_mont), out_idx,
+                                                    _stream_ptr(dev)), "merkle4_level")
+    return parents
+
+
+def merkle4_root(leaves_t, tag_mont: int, out_idx: int = 1, scratch=None):
+    """Root of the arity-4 tree over ``leaves_t`` (n_leaves x 32 B, n_leaves a power of 4)."""
+    import torch
+    ptr, n, dev = _dev_buffer(leaves_t, 32, "merkle4_root")
+    need = _lib.lib().hades252_merkle4_scratch_bytes(n)
+    if need == 0:
+        raise ValueError("merkle4_root: n_leaves must be a power of 4 (>= 4)")
+    if scratch is None:
+        scratch = torch.empty(need // 8, dtype=torch.int64, device=dev)
+    sptr = scratch.data_ptr()
+    sbytes = scratch.numel() * scratch.element_size()
+    root = torch.empty(4, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_merkle4_root_dev(ptr, n, sptr, sbytes, _tag_arr(tag_mont), out_idx,
+                                                   root.data_ptr(), _stream_ptr(dev)), "merkle4_root")
+    return root
+
+
+GEN_SEED = 0x4861646573323532
+
+
+def gen_b(n_elems: int, device, first_elem: int = 0, seed: int = GEN_SEED, out=None):
+    """Generator B on device: n_elems scalars starting at global element index."""
+    import torch
+    out = torch.empty((n_elems, 4), dtype=torch.int64, device=device) if out is None else out
+    with torch.cuda.device(out.device):
+        check(_lib.lib().hades252_gen_b_dev(out.data_ptr(), first_elem, n_elems, seed, _stream_ptr(out.device)),
+              "gen_b")
+    return out
+
+
+def gen_a(n_elems: int, device, first_elem: int = 0):
+    import torch
+    out = torch.empty((n_elems, 4), dtype=torch.int64, device=device)
+    with torch.cuda.device(out.device):
+        check(_lib.lib().hades252_gen_a_dev(out.data_ptr(), first_elem, n_elems, _stream_ptr(out.device)), "gen_a")
+    return out
+
+
+def digest(t, first_index: int = 0):
+    """256-bit position-sensitive digest of a device buffer (4 python ints)."""
+    import torch
+    ptr, n, dev = _dev_buffer(t, 8, "digest")
+    out = torch.empty(4, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_digest_dev(ptr, first_index, n, out.data_ptr(), _stream_ptr(dev)), "digest")
+    return [int(v) & 0xFFFFFFFFFFFFFFFF for v in out.cpu().tolist()]

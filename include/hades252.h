@@ -1,0 +1,122 @@
+/*
+ * hades252.h -- C ABI of libhades252 (MI355X / gfx950 batched Hades252 permutation).
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference (dusk-hades 0.24.1)
+ * has no FFI of its own; every entry point below names the reference interface it stands in
+ * for (paths relative to the reference crate root).  A Rust `Strategy<BlsScalar>` implementor
+ * binds these with a plain `extern "C"` block -- see INTEGRATION.md.
+ *
+ * Data formats
+ *   "Montgomery limbs": the in-memory `BlsScalar` -- 4 x u64 little-endian limbs of
+ *       value * 2^256 mod p, fully reduced to [0, p).  A state is WIDTH = 5 scalars = 20 u64 =
+ *       160 bytes; a batch is an array of states (AoS), permutation i at u64 offset 20*i.
+ *       This is exactly `&mut [BlsScalar]` with len = 5*n (zero-copy from Rust).
+ *   "canonical bytes": `BlsScalar::to_bytes()` -- 32 little-endian bytes of the value in [0, p)
+ *       (the format used at src/round_constants.rs:61-62).
+ *   Inputs that are not fully reduced are outside the reference's type invariant; the limb entry
+ *   points do not check them, the byte entry points reject them (HADES252_ERR_NOT_CANONICAL).
+ *
+ * Conventions
+ *   - All functions return HADES252_OK (0) or a negative HADES252_ERR_* code; nothing throws or
+ *     unwinds across the boundary (the reference builds with panic = 'abort', Cargo.toml:20).
+ *   - The caller owns every buffer.  Host-pointer functions are synchronous and keep no
+ *     pointer after returning.  `_dev` functions take device pointers valid on the CURRENT HIP
+ *     device, enqueue on `stream` (a hipStream_t, NULL = default stream) and return without
+ *     synchronising; buffers must stay alive until the stream has drained.
+ *   - Re-entrant: no mutable global state; any number of host threads may call concurrently
+ *     (the reference's strategy is a stateless ZST, src/strategies/scalar.rs:11-20).
+ *   - There is no CPU fallback: without a usable HIP device the calls fail with
+ *     HADES252_ERR_NO_DEVICE / HADES252_ERR_HIP.
+ */
+#ifndef HADES252_H
+#define HADES252_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HADES252_WIDTH 5              /* src/lib.rs:27 */
+#define HADES252_TOTAL_FULL_ROUNDS 8  /* src/lib.rs:21 */
+#define HADES252_PARTIAL_ROUNDS 59    /* src/lib.rs:25 */
+
+#define HADES252_OK 0
+#define HADES252_ERR_INVALID_ARG (-1)   /* NULL pointer with n > 0, bad round / index / device count */
+#define HADES252_ERR_HIP (-2)           /* a HIP runtime call failed; see hades252_last_hip_error() */
+#define HADES252_ERR_NOT_CANONICAL (-3) /* a canonical-bytes input encodes a value >= p */
+#define HADES252_ERR_NO_DEVICE (-4)     /* no HIP device visible */
+#define HADES252_ERR_SCRATCH (-5)       /* scratch buffer too small */
+
+/* kernel selectors for hades252_perm_batch_dev_ex (both produce identical bits) */
+#define HADES252_KERNEL_DEFAULT 0
+#define HADES252_KERNEL_LITERAL 1 /* the reference's round structure, 1972 Montgomery products */
+#define HADES252_KERNEL_FAST 2    /* scale-tracked small-integer MDS formulation */
+
+/* ---- meta --------------------------------------------------------------------------- */
+/* Strategy::rounds() (src/strategies.rs:160-162): TOTAL_FULL_ROUNDS + PARTIAL_ROUNDS = 67 */
+int hades252_rounds(void);
+int hades252_device_count(void);
+const char *hades252_strerror(int code);
+/* hipError_t of the most recent failing HIP call on this thread (0 if none) */
+int hades252_last_hip_error(void);
+const char *hades252_version(void);
+
+/* ---- Strategy::perm, batched (src/strategies.rs:140-157 via ScalarStrategy) -------------- */
+/* In place on host memory, Montgomery limbs.  n_perms == 1 is exactly
+ * `ScalarStrategy::new().perm(&mut state)` (README.md:60-61). */
+int hades252_perm_batch(uint64_t *states, size_t n_perms);
+/* In place on host memory, canonical bytes (5 x 32 B per state). */
+int hades252_perm_batch_bytes(uint8_t *states, size_t n_perms);
+/* In place on device memory, Montgomery limbs, asynchronous on `stream`. */
+int hades252_perm_batch_dev(void *d_states, size_t n_perms, void *stream);
+int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int kernel);
+/* Host batch sharded over the first n_devices GPUs (contiguous ranges, one host thread and
+ * stream per device, no collective).  n_devices <= 0 means all visible devices. */
+int hades252_perm_batch_multi(uint64_t *states, size_t n_perms, int n_devices);
+
+/* ---- the trait's per-operation methods, batched on device ------------------------------- */
+/* Strategy::add_round_key (src/strategies/scalar.rs:23-30) with the cursor at 5*round:
+ * word w of every state += ROUND_CONSTANTS[5*round + w].  0 <= round < 67. */
+int hades252_add_round_key_dev(void *d_states, size_t n_states, int round, void *stream);
+/* Strategy::quintic_s_box (src/strategies/scalar.rs:32-34) on n_scalars independent scalars. */
+int hades252_quintic_s_box_dev(void *d_scalars, size_t n_scalars, void *stream);
+/* Strategy::mul_matrix (src/strategies/scalar.rs:36-49) on every state. */
+int hades252_mul_matrix_dev(void *d_states, size_t n_states, void *stream);
+/* Strategy::apply_full_round / apply_partial_round (src/strategies.rs:107-119, :79-93). */
+int hades252_apply_full_round_dev(void *d_states, size_t n_states, int round, void *stream);
+int hades252_apply_partial_round_dev(void *d_states, size_t n_states, int round, void *stream);
+
+/* ---- wire format on device: BlsScalar::from_bytes / to_bytes ------------------------------ */
+/* d_bad_count (device int, may be NULL) is incremented once per input >= p; such inputs
+ * produce an all-zero scalar. */
+int hades252_from_bytes_dev(const void *d_bytes, void *d_limbs, size_t n_scalars, int *d_bad_count, void *stream);
+int hades252_to_bytes_dev(const void *d_limbs, void *d_bytes, size_t n_scalars, void *stream);
+
+/* ---- arity-4 Poseidon Merkle tree (caller shape of dusk-poseidon, README.md:9) ------------ */
+/* parent[i] = perm([tag, child[4i], .., child[4i+3]])[out_idx]; tag in Montgomery limbs.
+ * The external convention is tag = 2^4 - 1 = 15, out_idx = 1 (not pinned by the reference). */
+int hades252_merkle4_level_dev(const void *d_children, void *d_parents, size_t n_parents,
+                               const uint64_t tag_mont[4], int out_idx, void *stream);
+/* Whole tree, level by level; n_leaves must be a power of 4, >= 4.  d_scratch needs
+ * hades252_merkle4_scratch_bytes(n_leaves) bytes; the root (32 B) is written to d_root. */
+size_t hades252_merkle4_scratch_bytes(size_t n_leaves);
+int hades252_merkle4_root_dev(const void *d_leaves, size_t n_leaves, void *d_scratch, size_t scratch_bytes,
+                              const uint64_t tag_mont[4], int out_idx, void *d_root, void *stream);
+
+/* ---- synthetic inputs and digests (benchmark / verification plumbing) --------------------- */
+/* Generator B: scalar e (global element index first_elem + k) gets 4 splitmix64 limbs, top limb
+ * masked to 62 bits (always < p); see DESIGN.md.  Stateless, so shards generate independently. */
+int hades252_gen_b_dev(void *d_scalars, uint64_t first_elem, size_t n_elems, uint64_t seed, void *stream);
+/* Generator A: scalar e has value first_elem + k (Montgomery form). */
+int hades252_gen_a_dev(void *d_scalars, uint64_t first_elem, size_t n_elems, void *stream);
+/* Position-sensitive 256-bit digest of n_u64 words: with g = first_index + i the global index
+ * of word i, out[g % 4] += mix(word_i, g) (mod 2^64).  Additive over disjoint ranges, so
+ * shards combine by limb-wise wrapping addition.  d_out4 = 4 device u64, zeroed by the call. */
+int hades252_digest_dev(const void *d_words, uint64_t first_index, size_t n_u64, void *d_out4, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HADES252_H */

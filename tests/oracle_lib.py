@@ -1,0 +1,164 @@
+"""ctypes wrapper of oracle/_build/libhades_oracle.so for the tests (numpy uint64 in / out)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ORACLE_DIR, "_build", "libhades_oracle.so")
+GEN_SEED = 0x4861646573323532
+P = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+R = (1 << 256) % P
+M64 = (1 << 64) - 1
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build():
+    src = os.path.join(ORACLE_DIR, "hades_oracle.c")
+    hdr = os.path.join(ORACLE_DIR, "hades_oracle_constants.h")
+    if (not os.path.exists(SO)) or os.path.getmtime(SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["make", "-C", ORACLE_DIR], check=True, stdout=subprocess.DEVNULL)
+    return SO
+
+
+def limbs_of(m):
+    return [(m >> (64 * k)) & M64 for k in range(4)]
+
+
+def int_of(limbs):
+    return sum(int(limbs[k]) << (64 * k) for k in range(4))
+
+
+def _p(a):
+    return a.ctypes.data_as(_u64p)
+
+
+class Oracle:
+    def __init__(self, so):
+        self.l = ctypes.CDLL(so)
+        self.l.hades_oracle_init()
+        self.l.hades_oracle_from_bytes.restype = ctypes.c_int
+        self.ncpu = os.cpu_count() or 1
+
+    def perm_batch(self, states, threads=None):
+        """states: uint64 array, size multiple of 20; returns a permuted COPY."""
+        out = np.ascontiguousarray(states, dtype=np.uint64).copy()
+        assert out.size % 20 == 0
+        self.l.hades_oracle_perm_batch(_p(out), ctypes.c_size_t(out.size // 20),
+                                       ctypes.c_int(threads or self.ncpu))
+        return out
+
+    def perm_trace(self, state):
+        st = np.ascontiguousarray(state, dtype=np.uint64).copy()
+        tr = np.zeros(67 * 20, dtype=np.uint64)
+        self.l.hades_oracle_perm_trace(_p(st), _p(tr))
+        return st, tr.reshape(67, 5, 4)
+
+    def add_round_key(self, states, rnd):
+        out = np.ascontiguousarray(states, dtype=np.uint64).copy()
+        self.l.hades_oracle_add_round_key(_p(out), ctypes.c_size_t(out.size // 20), ctypes.c_int(rnd))
+        return out
+
+    def quintic_s_box(self, scalars):
+        out = np.ascontiguousarray(scalars, dtype=np.uint64).copy()
+        self.l.hades_oracle_quintic_s_box(_p(out), ctypes.c_size_t(out.size // 4))
+        return out
+
+    def mul_matrix(self, states):
+        out = np.ascontiguousarray(states, dtype=np.uint64).copy()
+        self.l.hades_oracle_mul_matrix(_p(out), ctypes.c_size_t(out.size // 20))
+        return out
+
+    def full_round(self, states, rnd):
+        st = self.add_round_key(states, rnd)
+        st = self.quintic_s_box(st)
+        return self.mul_matrix(st)
+
+    def partial_round(self, states, rnd):
+        st = self.add_round_key(states, rnd).reshape(-1, 5, 4)
+        st[:, 4, :] = self.quintic_s_box(st[:, 4, :].copy()).reshape(-1, 4)
+        return self.mul_matrix(st.reshape(-1))
+
+    def gen_b(self, first_elem, n_elems, seed=GEN_SEED):
+        out = np.zeros(n_elems * 4, dtype=np.uint64)
+        self.l.hades_oracle_gen_b(_p(out), ctypes.c_uint64(first_elem), ctypes.c_size_t(n_elems), ctypes.c_uint64(seed))
+        return out
+
+    def gen_a(self, first_elem, n_elems):
+        out = np.zeros(n_elems * 4, dtype=np.uint64)
+        self.l.hades_oracle_gen_a(_p(out), ctypes.c_uint64(first_elem), ctypes.c_size_t(n_elems))
+        return out
+
+    def merkle4_level(self, children, tag_mont, out_idx=1, threads=None):
+        ch = np.ascontiguousarray(children, dtype=np.uint64)
+        n = ch.size // 16
+        out = np.zeros(n * 4, dtype=np.uint64)
+        tag = np.array(limbs_of(tag_mont), dtype=np.uint64)
+        self.l.hades_oracle_merkle4_level(_p(ch), _p(out), ctypes.c_size_t(n), _p(tag), ctypes.c_int(out_idx),
+                                          ctypes.c_int(threads or self.ncpu))
+        return out
+
+    def merkle4_root(self, leaves, tag_mont, out_idx=1):
+        level = np.ascontiguousarray(leaves, dtype=np.uint64)
+        while level.size > 4:
+            level = self.merkle4_level(level, tag_mont, out_idx)
+        return level
+
+    def from_bytes(self, b32):
+        buf = (ctypes.c_uint8 * 32)(*b32)
+        out = np.zeros(4, dtype=np.uint64)
+        rc = self.l.hades_oracle_from_bytes(buf, _p(out))
+        return rc, out
+
+    def to_bytes(self, limbs):
+        a = np.ascontiguousarray(limbs, dtype=np.uint64)
+        buf = (ctypes.c_uint8 * 32)()
+        self.l.hades_oracle_to_bytes(_p(a), buf)
+        return bytes(buf)
+
+    def fr2(self, name, a, b):
+        x = np.array(limbs_of(a), dtype=np.uint64)
+        y = np.array(limbs_of(b), dtype=np.uint64)
+        o = np.zeros(4, dtype=np.uint64)
+        getattr(self.l, "hades_oracle_fr_" + name)(_p(x), _p(y), _p(o))
+        return int_of(o)
+
+    def fr1(self, name, a):
+        x = np.array(limbs_of(a), dtype=np.uint64)
+        o = np.zeros(4, dtype=np.uint64)
+        getattr(self.l, "hades_oracle_fr_" + name)(_p(x), _p(o))
+        return int_of(o)
+
+    def round_constant(self, i):
+        o = np.zeros(4, dtype=np.uint64)
+        self.l.hades_oracle_round_constant(ctypes.c_int(i), _p(o))
+        return int_of(o)
+
+    def mds(self, i, j):
+        o = np.zeros(4, dtype=np.uint64)
+        self.l.hades_oracle_mds(ctypes.c_int(i), ctypes.c_int(j), _p(o))
+        return int_of(o)
+
+
+def load():
+    return Oracle(build())
+
+
+def digest_ref(words, first_index=0):
+    """numpy restatement of hades252_digest_dev (include/hades252.h)."""
+    w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1)
+    idx = np.arange(w.size, dtype=np.uint64) + np.uint64(first_index)
+    with np.errstate(over="ignore"):
+        z = w ^ (idx * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0xD1B54A32D192ED03))
+        z = (z ^ (z >> np.uint64(32))) * np.uint64(0xD6E8FEB86659FD93)
+        z = (z ^ (z >> np.uint64(29))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = z ^ (z >> np.uint64(32))
+        out = [0, 0, 0, 0]
+        for k in range(4):
+            sel = (idx & np.uint64(3)) == np.uint64(k)
+            out[k] = int(z[sel].sum(dtype=np.uint64))
+    return out

@@ -1,0 +1,64 @@
+"""CPU tier: the C-ABI library builds, loads and exports every symbol include/hades252.h declares.
+No compute call is made here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "hades252.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hades252_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    syms = declared_symbols()
+    for must in ("hades252_perm_batch", "hades252_perm_batch_dev", "hades252_perm_batch_bytes",
+                 "hades252_merkle4_level_dev", "hades252_device_count", "hades252_strerror"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(hades_lib):
+    from hades252_amd import _lib
+    syms = declared_symbols()
+    assert set(syms) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), "missing export " + s
+
+
+def test_meta_calls_without_gpu(hades_lib):
+    assert hades_lib.hades252_rounds() == 67
+    assert hades_lib.hades252_strerror(0) == b"ok"
+    assert b"canonical" in hades_lib.hades252_strerror(-3)
+    assert hades_lib.hades252_version().startswith(b"hades252-amd")
+    # empty batches are a no-op success, like perm on zero states would be
+    assert hades_lib.hades252_perm_batch(None, 0) == 0
+    assert hades_lib.hades252_perm_batch_dev(None, 0, None) == 0
+    # NULL with n > 0 is an argument error, not a crash
+    assert hades_lib.hades252_perm_batch_dev(None, 4, None) == -1
+    assert hades_lib.hades252_merkle4_scratch_bytes(16) == 4 * 32 + 32
+    assert hades_lib.hades252_merkle4_scratch_bytes(8) == 0
+
+
+def test_no_cpu_fallback_in_product():
+    """The product package must not reference the oracle."""
+    pkg = os.path.join(ROOT, "hades252_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp", ".hpp", ".rs")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "hades_oracle" not in text and "hades_spec" not in text, f
+                assert "oracle_lib" not in text, f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from hades252_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()

@@ -1,0 +1,298 @@
+"""GPU tier: the HIP path, called through the C ABI, against the CPU oracle -- bit exact."""
+import ctypes
+import hashlib
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import hades_spec as S  # noqa: E402
+from oracle_lib import P, R, limbs_of, int_of, digest_ref  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = [1, 2]   # HADES252_KERNEL_LITERAL, HADES252_KERNEL_FAST
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def H(hades_lib):
+    from hades252_amd import strategy
+    return strategy
+
+
+def to_dev(torch, arr):
+    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint64).view(np.int64)).cuda()
+
+
+def to_host(t):
+    return t.cpu().numpy().view(np.uint64).reshape(-1)
+
+
+def kernel_available(hades_lib, torch, k):
+    t = torch.zeros(20, dtype=torch.int64, device="cuda")
+    return hades_lib.hades252_perm_batch_dev_ex(t.data_ptr(), 1, None, k) == 0
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_single_perm_kats(torch_cuda, hades_lib, H, kat, kernel):
+    """config 0/1: README-style single permutation, golden vectors."""
+    torch = torch_cuda
+    if not kernel_available(hades_lib, torch, kernel):
+        pytest.skip("kernel %d not built" % kernel)
+    strat = H.ScalarStrategy(kernel)
+    for s in kat["single"]:
+        st = to_dev(torch, sum([limbs_of(int(x, 16)) for x in s["in_mont"]], []))
+        strat.perm(st)
+        exp = sum([limbs_of(int(x, 16)) for x in s["out_mont"]], [])
+        assert list(map(int, to_host(st))) == exp
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1000, 4097])
+def test_ragged_batches(torch_cuda, hades_lib, H, oracle, kernel, n):
+    torch = torch_cuda
+    if not kernel_available(hades_lib, torch, kernel):
+        pytest.skip("kernel %d not built" % kernel)
+    inp = oracle.gen_b(1000 * n, 5 * n)
+    guard = np.full(40, 0xDEADBEEFCAFEF00D, dtype=np.uint64)
+    buf = to_dev(torch, np.concatenate([guard, inp, guard]))
+    view = buf[40:40 + 20 * n]
+    H.ScalarStrategy(kernel).perm(view)
+    got = to_host(buf)
+    assert (got[:40] == guard).all() and (got[-40:] == guard).all(), "wrote outside the batch"
+    assert (got[40:-40] == oracle.perm_batch(inp)).all()
+
+
+def test_empty_batch(torch_cuda, H):
+    t = torch_cuda.zeros(0, dtype=torch_cuda.int64, device="cuda")
+    H.ScalarStrategy().perm(t)
+
+
+def test_bad_length_rejected(torch_cuda, H):
+    # reference: copy_from_slice panics for len != WIDTH (scalar.rs:48)
+    t = torch_cuda.zeros(19, dtype=torch_cuda.int64, device="cuda")
+    with pytest.raises(ValueError):
+        H.ScalarStrategy().perm(t)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_batch_digests_golden(torch_cuda, hades_lib, H, kat, kernel):
+    torch = torch_cuda
+    if not kernel_available(hades_lib, torch, kernel):
+        pytest.skip("kernel %d not built" % kernel)
+    for name in ("gen_a", "gen_b"):
+        n = kat[name]["n"]
+        buf = H.gen_a(5 * n, "cuda") if name == "gen_a" else H.gen_b(5 * n, "cuda")
+        assert hashlib.sha256(to_host(buf).tobytes()).hexdigest() == kat[name]["sha256_in"]
+        H.ScalarStrategy(kernel).perm(buf)
+        assert hashlib.sha256(to_host(buf).tobytes()).hexdigest() == kat[name]["sha256_out"]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_edge_values(torch_cuda, hades_lib, H, oracle, kernel):
+    """0, 1, p-1, R, all-ones-ish limbs in every word position, plus random."""
+    torch = torch_cuda
+    if not kernel_available(hades_lib, torch, kernel):
+        pytest.skip("kernel %d not built" % kernel)
+    rng = random.Random(1)
+    edge = [0, 1, 2, P - 1, P - 2, R, P - R, (1 << 255) % P, (1 << 254) - 1, 0xFFFFFFFF, P - (1 << 32),
+            0xFFFFFFFF00000000, (P - 1) // 2, 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF]
+    states = []
+    for _ in range(2048):
+        states.append([rng.choice(edge) if rng.random() < 0.7 else rng.randrange(P) for _ in range(5)])
+    inp = np.array([l for st in states for v in st for l in limbs_of(v)], dtype=np.uint64)
+    buf = to_dev(torch, inp)
+    H.ScalarStrategy(kernel).perm(buf)
+    assert (to_host(buf) == oracle.perm_batch(inp)).all()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_config2_2pow20_bit_exact(torch_cuda, hades_lib, H, oracle, kernel):
+    """BASELINE config[1]: 2^20 independent permutations, every output bit compared."""
+    torch = torch_cuda
+    if not kernel_available(hades_lib, torch, kernel):
+        pytest.skip("kernel %d not built" % kernel)
+    n = 1 << 20
+    buf = H.gen_b(5 * n, "cuda")
+    inp = to_host(buf).copy()
+    assert (inp[:20 * 4096] == oracle.gen_b(0, 5 * 4096)).all()
+    H.ScalarStrategy(kernel).perm(buf)
+    got = to_host(buf)
+    exp = oracle.perm_batch(inp)
+    assert (got == exp).all()
+
+
+def test_per_op_kernels(torch_cuda, H, oracle):
+    """Strategy::add_round_key / quintic_s_box / mul_matrix / apply_*_round vs the oracle."""
+    torch = torch_cuda
+    n = 777
+    inp = oracle.gen_b(31337, 5 * n)
+    strat = H.ScalarStrategy()
+    for rnd in (0, 3, 4, 35, 62, 63, 66):
+        buf = to_dev(torch, inp)
+        it = H.RoundConstantsIter(5 * rnd)
+        strat.add_round_key(it, buf)
+        assert it.pos == 5 * rnd + 5
+        assert (to_host(buf) == oracle.add_round_key(inp, rnd)).all()
+        buf = to_dev(torch, inp)
+        strat.apply_full_round(H.RoundConstantsIter(5 * rnd), buf)
+        assert (to_host(buf) == oracle.full_round(inp, rnd)).all()
+        buf = to_dev(torch, inp)
+        strat.apply_partial_round(H.RoundConstantsIter(5 * rnd), buf)
+        assert (to_host(buf) == oracle.partial_round(inp, rnd)).all()
+    buf = to_dev(torch, inp)
+    strat.quintic_s_box(buf)
+    assert (to_host(buf) == oracle.quintic_s_box(inp)).all()
+    buf = to_dev(torch, inp)
+    strat.mul_matrix(H.RoundConstantsIter(), buf)
+    assert (to_host(buf) == oracle.mul_matrix(inp)).all()
+    with pytest.raises(RuntimeError, match="out of ARK constants"):
+        strat.add_round_key(H.RoundConstantsIter(335), buf)
+
+
+def test_perm_is_the_composition_of_rounds(torch_cuda, H, oracle):
+    """The trait's provided perm (strategies.rs:140-157) replayed over the per-round entry
+    points equals the fused kernel."""
+    torch = torch_cuda
+    inp = oracle.gen_b(5, 5 * 300)
+    a, b = to_dev(torch, inp), to_dev(torch, inp)
+    H.ScalarStrategy().perm(a)
+    H.ScalarStrategy().perm_stepwise(b)
+    assert torch.equal(a, b)
+
+
+def test_kernels_agree_at_scale(torch_cuda, hades_lib, H):
+    """Two independent device implementations, 2^22 permutations, digest of all outputs."""
+    torch = torch_cuda
+    if not kernel_available(hades_lib, torch, 2):
+        pytest.skip("fast kernel not built")
+    n = 1 << 22
+    a = H.gen_b(5 * n, "cuda")
+    b = a.clone()
+    H.ScalarStrategy(1).perm(a)
+    H.ScalarStrategy(2).perm(b)
+    assert H.digest(a) == H.digest(b)
+    assert torch.equal(a, b)
+
+
+def test_split_invariance(torch_cuda, H):
+    """Permuting a batch in one call or in ragged pieces gives the same bytes (no cross-lane state)."""
+    torch = torch_cuda
+    n = 100003
+    a = H.gen_b(5 * n, "cuda")
+    b = a.clone()
+    H.ScalarStrategy().perm(a)
+    flat = b.view(-1)
+    cuts = [0, 1, 64, 1000, 65537, n]
+    for lo, hi in zip(cuts, cuts[1:]):
+        H.ScalarStrategy().perm(flat[20 * lo:20 * hi])
+    assert torch.equal(a, b)
+
+
+def test_bytes_wire_format(torch_cuda, hades_lib, H, oracle):
+    torch = torch_cuda
+    rng = random.Random(3)
+    vals = [0, 1, P - 1, R] + [rng.randrange(P) for _ in range(996)]
+    raw = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint64).copy()
+    dev = to_dev(torch, raw)
+    limbs = H.from_bytes(dev)
+    got = to_host(limbs).reshape(-1, 4)
+    for k in (0, 1, 2, 3, 500, 999):
+        assert int_of(got[k]) == vals[k] * R % P
+    back = H.to_bytes(limbs)
+    assert (to_host(back) == raw).all()
+    # host entry point: whole permutation on canonical bytes
+    n = 200
+    host = raw[:n * 20].copy()
+    rc = hades_lib.hades252_perm_batch_bytes(host.ctypes.data_as(ctypes.c_void_p), n)
+    assert rc == 0
+    for i in (0, 7, 199):
+        exp = S.perm(vals[5 * i:5 * i + 5])
+        got_vals = [int_of(host[20 * i + 4 * w:20 * i + 4 * w + 4]) for w in range(5)]
+        assert got_vals == exp
+    # non-canonical input (>= p) is rejected and the buffer is left untouched
+    bad = raw[:40].copy()
+    bad[4:8] = np.array(limbs_of(P), dtype=np.uint64)
+    keep = bad.copy()
+    assert hades_lib.hades252_perm_batch_bytes(bad.ctypes.data_as(ctypes.c_void_p), 2) == -3
+    assert (bad == keep).all()
+    with pytest.raises(ValueError):
+        H.from_bytes(to_dev(torch, bad))
+
+
+def test_host_entry_points(torch_cuda, hades_lib, H, oracle):
+    n = 5000
+    inp = oracle.gen_b(99, 5 * n)
+    exp = oracle.perm_batch(inp)
+    a = inp.copy()
+    H.ScalarStrategy().perm(a)                       # numpy -> hades252_perm_batch
+    assert (a == exp).all()
+    b = inp.copy()
+    assert hades_lib.hades252_perm_batch_multi(b.ctypes.data_as(ctypes.c_void_p), n, 1) == 0
+    assert (b == exp).all()
+    ndev = hades_lib.hades252_device_count()
+    assert ndev >= 1
+    c = inp.copy()
+    assert hades_lib.hades252_perm_batch_multi(c.ctypes.data_as(ctypes.c_void_p), n, 0) == 0
+    assert (c == exp).all()
+    assert hades_lib.hades252_perm_batch_multi(c.ctypes.data_as(ctypes.c_void_p), n, ndev + 1) == -1
+
+
+def test_host_path_chunked(torch_cuda, hades_lib, H, oracle):
+    """More than one 2^18 chunk: exercises the double-buffered H2D / kernel / D2H pipeline."""
+    n = (1 << 18) * 2 + 12345
+    buf = H.gen_b(5 * n, "cuda")
+    inp = to_host(buf).copy()
+    H.ScalarStrategy().perm(buf)
+    host = inp.copy()
+    H.ScalarStrategy().perm(host)
+    assert (host == to_host(buf)).all()
+
+
+def test_merkle(torch_cuda, H, oracle, kat):
+    torch = torch_cuda
+    g = kat["merkle4_root_mont"]
+    tag = S.to_mont(g["tag"])
+    for n_str, root_hex in g["leaves_gen_b"].items():
+        leaves = H.gen_b(int(n_str), "cuda")
+        root = H.merkle4_root(leaves, tag, g["out_idx"])
+        assert hex(int_of(to_host(root))) == root_hex
+    # one level, ragged count, every output index
+    n_par = 1000
+    ch = oracle.gen_b(4242, 4 * n_par)
+    for out_idx in range(5):
+        par = H.merkle4_level(to_dev(torch, ch), tag, out_idx)
+        assert (to_host(par) == oracle.merkle4_level(ch, tag, out_idx)).all()
+    # 4^8 leaves: device root == oracle root
+    n = 4 ** 8
+    leaves = H.gen_b(n, "cuda")
+    root = H.merkle4_root(leaves, tag, 1)
+    assert (to_host(root) == oracle.merkle4_root(oracle.gen_b(0, n), tag, 1)).all()
+    with pytest.raises(ValueError):
+        H.merkle4_root(H.gen_b(8, "cuda"), tag, 1)
+
+
+def test_generators_and_digest(torch_cuda, H, oracle):
+    a = H.gen_a(1000, "cuda", first_elem=17)
+    assert (to_host(a) == oracle.gen_a(17, 1000)).all()
+    b = H.gen_b(100001, "cuda", first_elem=12345)
+    hb = to_host(b)
+    assert (hb == oracle.gen_b(12345, 100001)).all()
+    assert H.digest(b) == digest_ref(hb)
+    assert H.digest(b, first_index=6) == digest_ref(hb, 6)
+    # additivity over a split (how shards combine)
+    flat = b.view(-1)
+    cut = 4 * 5003
+    d1, d2 = H.digest(flat[:cut], 0), H.digest(flat[cut:], cut)
+    assert [(x + y) & 0xFFFFFFFFFFFFFFFF for x, y in zip(d1, d2)] == H.digest(b)
