@@ -68,6 +68,13 @@ def lib() -> ctypes.CDLL:
             raise RuntimeError(
                 "libhades252.so is missing (%s). Build it with `python -m hades252_amd.build`; "
                 "hades252_amd has no CPU fallback." % LIB_PATH)
+        # torch bundles its own HIP runtime; it must be the one this process uses (device pointers
+        # and streams are torch's), so make sure it is loaded before libhades252's dependency on
+        # libamdhip64 is resolved.  A C/Rust host links the system runtime directly.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)           # AttributeError if the symbol is not exported

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <thread>
@@ -26,6 +27,10 @@ __device__ const uint32_t d_mds_mont[25][8] = HADES_MDS_MONT_INIT;
 // R^2 mod p (from_raw / from_bytes multiplier) and 1 (to_bytes multiplier), 8 x u32
 __device__ const uint32_t d_r2[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu,
                                      0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
+
+#ifdef HADES_HAVE_FAST
+__device__ const FastTables d_fast = {HADES_FAST_FULL_INIT, HADES_FAST_PART_INIT, HADES_FAST_FINAL_F};
+#endif
 
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
@@ -122,6 +127,35 @@ __global__ void __launch_bounds__(kBlock) k_merkle4_level_literal(const uint8_t 
     wave_store_records<1>(parents, rec0, n_parents, slab, out);
 }
 
+#ifdef HADES_HAVE_FAST
+// The shipped hot path: one permutation per lane, scale-tracked formulation (hades_fast.cuh).
+template <int MINW>
+__global__ void __launch_bounds__(kBlock, MINW) k_perm_fast(uint8_t *__restrict__ states, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<5>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr st[5];
+    wave_load_records<5>(states, rec0, n, slab, st);
+    Fr out[5];
+    fast_perm<5>(&d_fast, st, out, 0);
+    wave_store_records<5>(states, rec0, n, slab, out);
+}
+
+__global__ void __launch_bounds__(kBlock) k_merkle4_level_fast(const uint8_t *__restrict__ children,
+                                                               uint8_t *__restrict__ parents, size_t n_parents,
+                                                               Fr tag, int out_idx) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<4>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr ch[4];
+    wave_load_records<4>(children, rec0, n_parents, slab, ch);
+    Fr st[5] = {tag, ch[0], ch[1], ch[2], ch[3]};
+    Fr out[1];
+    fast_perm<1>(&d_fast, st, out, out_idx);
+    wave_store_records<1>(parents, rec0, n_parents, slab, out);
+}
+#endif
+
 __device__ __forceinline__ uint64_t splitmix_limb(uint64_t seed, uint64_t idx) {
     uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -201,6 +235,30 @@ static thread_local int tl_last_hip_error = 0;
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 static inline size_t lds_for(int nw) { return (size_t)kWavesPerBlock * lds_wave_bytes(nw); }
 static constexpr size_t kMaxLaunchRecords = (size_t)1 << 30;   // grid.x * 256 per launch
+
+#ifdef HADES_HAVE_FAST
+static int launch_perm_fast(uint8_t *states, size_t n, hipStream_t s) {
+    // development knob: HADES252_FAST_MINW picks the occupancy variant (waves per SIMD)
+    static const int minw = []() {
+        const char *e = getenv("HADES252_FAST_MINW");
+        return e ? atoi(e) : 4;
+    }();
+    switch (minw) {
+        case 2: hipLaunchKernelGGL(k_perm_fast<2>, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, states, n); break;
+        case 3: hipLaunchKernelGGL(k_perm_fast<3>, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, states, n); break;
+        case 5: hipLaunchKernelGGL(k_perm_fast<5>, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, states, n); break;
+        case 6: hipLaunchKernelGGL(k_perm_fast<6>, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, states, n); break;
+        default: hipLaunchKernelGGL(k_perm_fast<4>, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, states, n); break;
+    }
+    return HADES252_OK;
+}
+static int launch_merkle4_level_fast(const uint8_t *children, uint8_t *parents, size_t n, Fr tag, int out_idx,
+                                     hipStream_t s) {
+    hipLaunchKernelGGL(k_merkle4_level_fast, dim3(blocks_for(n)), dim3(kBlock), lds_for(4), s, children, parents, n,
+                       tag, out_idx);
+    return HADES252_OK;
+}
+#endif
 
 static int check_device() {
     int n = 0;
