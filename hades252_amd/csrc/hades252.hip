@@ -29,7 +29,7 @@ __device__ const uint32_t d_r2[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b
                                      0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
 
 #ifdef HADES_HAVE_FAST
-__device__ const FastTables d_fast = {HADES_FAST_FULL_INIT, HADES_FAST_PART_INIT, HADES_FAST_FINAL_F};
+__device__ const FastTables d_fast = {HADES_FAST_ROUND_INIT, HADES_FAST_FINAL_F};
 #endif
 
 constexpr int kBlock = 256;

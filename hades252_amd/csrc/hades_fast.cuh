@@ -19,10 +19,12 @@
 //     rounds one extra constant product K_r brings the S-boxed word back to the common scale.
 //     One product with FINAL_F at the end returns value * 2^256, which is then fully reduced --
 //     the unique in-memory BlsScalar.
-//  4. Partial-round ARK on words 0..3 is pushed through the linear layer (D_r seeds the
-//     accumulators).
+//  4. Every product and every linear-layer row runs on ONE 64-bit accumulator (finely integrated
+//     product scanning), so a product in flight needs its two operands, nine quotient digits and
+//     two accumulator registers instead of an 18-column array: the kernel fits 4+ waves per SIMD,
+//     which the VALU needs to reach its ~3.4-cycle issue rate for v_mad_u64_u32.
 //
-// Register budget: state 5 x 9 VGPRs; one product in flight needs <= 36 (columns) + 18.
+// Register budget: state 5 x 9 VGPRs + ~30 for the product in flight.
 // Constants are wave-uniform: scalar loads (SMEM) into SGPRs, consumed directly as
 // v_mad_u64_u32 operands.
 #pragma once
@@ -43,10 +45,20 @@ __device__ static constexpr uint32_t P29[kNL] = HADES_P29;
 __device__ static constexpr uint32_t MDS_SMALL[5][5] = HADES_FAST_MDS_SMALL;
 
 struct FastTables {
-    uint32_t full[8][48];     // [round][word*9 + limb], rounds 0..3 then 63..66
-    uint32_t part[59][64];    // {A4[9], K[9], D[5][9], pad}
+    uint32_t round[67][64];   // per round {A[5][9], K[9], pad}: scaled ARK constants, rescale factor
     uint32_t final_f[kNL + 7];
 };
+
+// One limb product accumulated in place; hipcc selects a single v_mad_u64_u32 for this shape
+// as long as both factors are provably 32-bit (see limb_fence).
+__device__ __forceinline__ void mac(uint64_t &acc, uint32_t a, uint32_t b) { acc += (uint64_t)a * b; }
+__device__ __forceinline__ void mac_s(uint64_t &acc, uint32_t a, uint32_t b_uniform) { acc += (uint64_t)a * b_uniform; }
+
+// Zero-instruction fence on one limb: makes the value an opaque 32-bit VGPR.  Without it hipcc
+// carries limbs across the round loop's back-edge as 64-bit values (zext(trunc(acc) & mask) is
+// folded to a 64-bit AND, the PHI loses the known-zero high half) and every limb product of the
+// next round turns into a 64 x 32 multiply: two mads and two moves.
+__device__ __forceinline__ void limb_fence(uint32_t &x) { asm volatile("" : "+v"(x)); }
 
 // ---- 8 x 32 <-> 9 x 29 ---------------------------------------------------------------------
 __device__ __forceinline__ F29 to_f29(const Fr &a) {
@@ -79,75 +91,86 @@ __device__ __forceinline__ Fr from_f29(const F29 &a) {
 }
 
 // ---- Montgomery product, Rp = 2^261 ----------------------------------------------------------
+// Finely integrated product scanning: ONE 64-bit accumulator walks the 18 columns; column k
+// receives its limb products, the reduction terms m_i * p_{k-i} of the quotient digits already
+// known, then (k < 9) yields the next digit m_k = -acc mod 2^29 (p == 1 mod 2^29, so
+// -p^-1 == -1) or (k >= 9) a result limb.  Every limb product is one v_mad_u64_u32 on the
+// accumulator; a column costs two extra VALU ops (digit / limb, shift).  Live registers: the two
+// operands, nine digits and the accumulator -- no column array.
 // Inputs: limbs < 2^30 (lazy), values < 2^258.  Output: limbs < 2^29, value < 2^256.
-// Column bound: 9 * 2^60 + 9 * 2^58 + carry < 2^64.
-__device__ __forceinline__ F29 mont_reduce(uint64_t (&t)[2 * kNL]) {
+// Column bound: 9 * 2^60 + 8 * 2^58 + carry < 2^64.
+template <bool SQR>
+__device__ __forceinline__ F29 mont_fips(const F29 &a, const F29 &b) {
+    uint32_t m[kNL];
+    uint32_t d[kNL];                       // 2 * a (squaring only)
+    if constexpr (SQR) {
 #pragma unroll
-    for (int k = 0; k < kNL; k++) {
-        uint32_t m = (0u - (uint32_t)t[k]) & kMask29;        // -t_k * p^-1 mod 2^29, p == 1 mod 2^29
-        t[k] += m;                                           // m * p_0, p_0 = 1
-#pragma unroll
-        for (int j = 1; j < kNL; j++) t[k + j] += (uint64_t)m * P29[j];
-        t[k + 1] += t[k] >> kLB;                             // exact: low 29 bits are zero
+        for (int i = 0; i < kNL; i++) d[i] = a.l[i] << 1;
     }
     F29 r;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < kNL - 1; k++) {
-        r.l[k] = (uint32_t)t[kNL + k] & kMask29;
-        t[kNL + k + 1] += t[kNL + k] >> kLB;
+    for (int k = 0; k < 2 * kNL - 1; k++) {
+        const int lo = k < kNL ? 0 : k - kNL + 1, hi = k < kNL ? k : kNL - 1;
+        if constexpr (SQR) {
+#pragma unroll
+            for (int i = lo; i <= hi; i++) {
+                int j = k - i;
+                if (i < j) mac(acc, a.l[i], d[j]);
+                if (i == j) mac(acc, a.l[i], a.l[i]);
+            }
+        } else {
+#pragma unroll
+            for (int i = lo; i <= hi; i++) mac(acc, a.l[i], b.l[k - i]);
+        }
+#pragma unroll
+        for (int i = lo; i <= hi; i++)
+            if (k - i >= 1) mac_s(acc, m[i], P29[k - i]);
+        if (k < kNL) {
+            m[k] = (0u - (uint32_t)acc) & kMask29;
+            acc = (acc + kMask29) >> kLB;           // == (acc + m_k * p_0) >> 29, exact
+        } else {
+            r.l[k - kNL] = (uint32_t)acc & kMask29;
+            acc >>= kLB;
+        }
     }
-    r.l[kNL - 1] = (uint32_t)t[2 * kNL - 1];
+    r.l[kNL - 1] = (uint32_t)acc;
     return r;
 }
 
-__device__ __forceinline__ F29 mont_mul(const F29 &a, const F29 &b) {
-    uint64_t t[2 * kNL];
-#pragma unroll
-    for (int k = 0; k < 2 * kNL; k++) t[k] = 0;
-#pragma unroll
-    for (int i = 0; i < kNL; i++)
-#pragma unroll
-        for (int j = 0; j < kNL; j++) t[i + j] += (uint64_t)a.l[i] * b.l[j];
-    return mont_reduce(t);
-}
+__device__ __forceinline__ F29 mont_mul(const F29 &a, const F29 &b) { return mont_fips<false>(a, b); }
 
-__device__ __forceinline__ F29 mont_sqr(const F29 &a) {
-    uint64_t t[2 * kNL];
+// product with a wave-uniform constant (limbs in SGPRs)
+__device__ __forceinline__ F29 mont_mul_const(const F29 &a, const uint32_t *c) {
+    uint32_t m[kNL];
+    F29 r;
+    uint64_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < 2 * kNL; k++) t[k] = 0;
-    uint32_t d[kNL];
+    for (int k = 0; k < 2 * kNL - 1; k++) {
+        const int lo = k < kNL ? 0 : k - kNL + 1, hi = k < kNL ? k : kNL - 1;
 #pragma unroll
-    for (int i = 0; i < kNL; i++) d[i] = a.l[i] << 1;       // < 2^31
+        for (int i = lo; i <= hi; i++) mac_s(acc, a.l[i], c[k - i]);
 #pragma unroll
-    for (int i = 0; i < kNL; i++) {
-        t[2 * i] += (uint64_t)a.l[i] * a.l[i];
-#pragma unroll
-        for (int j = i + 1; j < kNL; j++) t[i + j] += (uint64_t)a.l[i] * d[j];
+        for (int i = lo; i <= hi; i++)
+            if (k - i >= 1) mac_s(acc, m[i], P29[k - i]);
+        if (k < kNL) {
+            m[k] = (0u - (uint32_t)acc) & kMask29;
+            acc = (acc + kMask29) >> kLB;
+        } else {
+            r.l[k - kNL] = (uint32_t)acc & kMask29;
+            acc >>= kLB;
+        }
     }
-    return mont_reduce(t);
+    r.l[kNL - 1] = (uint32_t)acc;
+    return r;
 }
+__device__ __forceinline__ F29 mont_sqr(const F29 &a) { return mont_fips<true>(a, a); }
 
 // v^5 / Rp^4
 __device__ __forceinline__ F29 sbox29(const F29 &v) {
     F29 v2 = mont_sqr(v);
     F29 v4 = mont_sqr(v2);
     return mont_mul(v4, v);
-}
-
-// One-limb Montgomery step + carry normalisation of 9 accumulator columns (each < 2^59):
-// returns (T + m p) / 2^29 with limbs < 2^29.  T < 2^275 => result < 2^256.
-__device__ __forceinline__ F29 redc1_normalize(uint64_t (&t)[kNL]) {
-    uint32_t m = (0u - (uint32_t)t[0]) & kMask29;
-    uint64_t carry = (t[0] + m) >> kLB;
-    F29 r;
-#pragma unroll
-    for (int j = 1; j < kNL; j++) {
-        uint64_t v = t[j] + (uint64_t)m * P29[j] + carry;
-        r.l[j - 1] = (uint32_t)v & kMask29;
-        carry = v >> kLB;
-    }
-    r.l[kNL - 1] = (uint32_t)carry;
-    return r;
 }
 
 __device__ __forceinline__ F29 load_f29(const uint32_t *p) {
@@ -162,48 +185,54 @@ __device__ __forceinline__ void add_lazy(F29 &x, const F29 &c) {
     for (int k = 0; k < kNL; k++) x.l[k] += c.l[k];
 }
 
-// Y = C * X (+ seed), then REDC1 + normalise every word.
-template <bool SEED>
-__device__ __forceinline__ void small_mds(F29 (&st)[5], const uint32_t *seed /* [5][9] */) {
-    F29 out[5];
+// Row i of Y = C * X followed by a one-limb Montgomery step and carry normalisation, again on a
+// single accumulator: returns (Y_i + m p) / 2^29 with limbs < 2^29.
+// Input limbs < 2^30, C < 2^17: columns < 2^50 + 2^58; Y_i < 2^275 => result < 2^256.
+template <int I>
+__device__ __forceinline__ F29 small_mds_row(const F29 (&st)[5]) {
+    uint64_t acc = 0;
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
-        uint64_t t[kNL];
+    for (int j = 0; j < 5; j++) mac_s(acc, st[j].l[0], MDS_SMALL[I][j]);
+    const uint32_t m = (0u - (uint32_t)acc) & kMask29;
+    acc = (acc + kMask29) >> kLB;
+    F29 r;
 #pragma unroll
-        for (int k = 0; k < kNL; k++) {
-            t[k] = SEED ? (uint64_t)seed[i * kNL + k] : 0;
+    for (int k = 1; k < kNL; k++) {
 #pragma unroll
-            for (int j = 0; j < 5; j++) t[k] += (uint64_t)st[j].l[k] * MDS_SMALL[i][j];
-        }
-        out[i] = redc1_normalize(t);
+        for (int j = 0; j < 5; j++) mac_s(acc, st[j].l[k], MDS_SMALL[I][j]);
+        mac_s(acc, m, P29[k]);
+        r.l[k - 1] = (uint32_t)acc & kMask29;
+        acc >>= kLB;
     }
+    r.l[kNL - 1] = (uint32_t)acc;
+    return r;
+}
+
+__device__ __forceinline__ void small_mds(F29 (&st)[5]) {
+    F29 o0 = small_mds_row<0>(st), o1 = small_mds_row<1>(st), o2 = small_mds_row<2>(st),
+        o3 = small_mds_row<3>(st), o4 = small_mds_row<4>(st);
+    st[0] = o0; st[1] = o1; st[2] = o2; st[3] = o3; st[4] = o4;
+}
+
+// One round.  ARK touches all five words in both round kinds (reference src/strategies.rs:86,
+// :111); full rounds S-box every word, partial rounds the last word only, which then takes the
+// rescale product.  `full` is wave-uniform, so the branches are scalar.
+__device__ __forceinline__ void fast_round(const uint32_t *rec, bool full, F29 (&st)[5]) {
 #pragma unroll
-    for (int i = 0; i < 5; i++) st[i] = out[i];
-}
-
-template <int W>
-__device__ __forceinline__ void full_round_word(const uint32_t *rec, F29 (&st)[5]) {
-    add_lazy(st[W], load_f29(rec + W * kNL));
-    st[W] = sbox29(st[W]);
-}
-
-__device__ __forceinline__ void fast_full_round(const FastTables *T, int idx, F29 (&st)[5]) {
-    const uint32_t *rec = T->full[idx];
-    full_round_word<0>(rec, st);
-    full_round_word<1>(rec, st);
-    full_round_word<2>(rec, st);
-    full_round_word<3>(rec, st);
-    full_round_word<4>(rec, st);
-    small_mds<false>(st, nullptr);
-}
-
-__device__ __forceinline__ void fast_partial_round(const FastTables *T, int idx, F29 (&st)[5]) {
-    const uint32_t *rec = T->part[idx];
-    F29 w = st[4];
-    add_lazy(w, load_f29(rec));
-    w = sbox29(w);
-    st[4] = mont_mul(w, load_f29(rec + kNL));
-    small_mds<true>(st, rec + 2 * kNL);
+    for (int w = 0; w < 5; w++) add_lazy(st[w], load_f29(rec + w * kNL));
+    if (full) {
+        st[0] = sbox29(st[0]);
+        st[1] = sbox29(st[1]);
+        st[2] = sbox29(st[2]);
+        st[3] = sbox29(st[3]);
+    }
+    st[4] = sbox29(st[4]);
+    if (!full) st[4] = mont_mul_const(st[4], rec + 5 * kNL);
+    small_mds(st);
+#pragma unroll
+    for (int w = 0; w < 5; w++)
+#pragma unroll
+        for (int k = 0; k < kNL; k++) limb_fence(st[w].l[k]);
 }
 
 // in: 5 BlsScalars (Montgomery 2^256 form, fully reduced); out: same format, fully reduced.
@@ -212,15 +241,10 @@ __device__ __forceinline__ void fast_perm(const FastTables *T, const Fr (&in)[5]
     F29 st[5];
 #pragma unroll
     for (int w = 0; w < 5; w++) st[w] = to_f29(in[w]);
-    // one loop, two bodies: each round body exists once in the instruction stream (the
-    // branch is wave-uniform), so the whole kernel stays inside the instruction cache
+    // one loop, one body: every piece of round code exists once in the instruction stream, so the
+    // whole kernel stays inside the instruction cache
 #pragma unroll 1
-    for (int r = 0; r < 67; r++) {
-        if (r < 4 || r >= 63)
-            fast_full_round(T, r < 4 ? r : r - 59, st);
-        else
-            fast_partial_round(T, r - 4, st);
-    }
+    for (int r = 0; r < 67; r++) fast_round(T->round[r], r < 4 || r >= 63, st);
     F29 f = load_f29(T->final_f);
     if constexpr (NOUT == 5) {
 #pragma unroll
