@@ -36,6 +36,21 @@ ALGO_BYTES_PER_PERM = 320
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak, MI355X_MICROARCH.md
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 256))
+
+
 def cpu_baseline_and_check(H, torch, device, n_sample: int):
     """Time the CPU oracle on the first n_sample permutations of the workload and use its
     output to check the GPU path.  The oracle is used here only as baseline + checker."""
@@ -43,7 +58,7 @@ def cpu_baseline_and_check(H, torch, device, n_sample: int):
     import numpy as np
     import oracle_lib
     orc = oracle_lib.load()
-    cores = min(os.cpu_count() or 1, 256)
+    cores = usable_cores()
     inp = orc.gen_b(0, 5 * n_sample)
     # single thread on a smaller slice, all cores on the whole sample
     n1 = max(1024, n_sample // 64)

@@ -129,8 +129,9 @@ __global__ void __launch_bounds__(kBlock) k_merkle4_level_literal(const uint8_t 
 
 #ifdef HADES_HAVE_FAST
 // The shipped hot path: one permutation per lane, scale-tracked formulation (hades_fast.cuh).
-template <int MINW>
-__global__ void __launch_bounds__(kBlock, MINW) k_perm_fast(uint8_t *__restrict__ states, size_t n) {
+// __launch_bounds__(256, 4): 4 waves per SIMD = at most 128 VGPRs; the kernel needs 108 and does
+// not spill.  (2 waves/SIMD: same speed; 5: spills, 6 % slower; 6: 35 % slower -- measured.)
+__global__ void __launch_bounds__(kBlock, 4) k_perm_fast(uint8_t *__restrict__ states, size_t n) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *slab = wave_slab<5>(lds);
     size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(kBlock, MINW) k_perm_fast(uint8_t *__restrict_
     wave_store_records<5>(states, rec0, n, slab, out);
 }
 
-__global__ void __launch_bounds__(kBlock) k_merkle4_level_fast(const uint8_t *__restrict__ children,
+__global__ void __launch_bounds__(kBlock, 4) k_merkle4_level_fast(const uint8_t *__restrict__ children,
                                                                uint8_t *__restrict__ parents, size_t n_parents,
                                                                Fr tag, int out_idx) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -238,18 +239,7 @@ static constexpr size_t kMaxLaunchRecords = (size_t)1 << 30;   // grid.x * 256 p
 
 #ifdef HADES_HAVE_FAST
 static int launch_perm_fast(uint8_t *states, size_t n, hipStream_t s) {
-    // development knob: HADES252_FAST_MINW picks the occupancy variant (waves per SIMD)
-    static const int minw = []() {
-        const char *e = getenv("HADES252_FAST_MINW");
-        return e ? atoi(e) : 4;
-    }();
-    switch (minw) {
-        case 2: hipLaunchKernelGGL(k_perm_fast<2>, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, states, n); break;
-        case 3: hipLaunchKernelGGL(k_perm_fast<3>, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, states, n); break;
-        case 5: hipLaunchKernelGGL(k_perm_fast<5>, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, states, n); break;
-        case 6: hipLaunchKernelGGL(k_perm_fast<6>, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, states, n); break;
-        default: hipLaunchKernelGGL(k_perm_fast<4>, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, states, n); break;
-    }
+    hipLaunchKernelGGL(k_perm_fast, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, states, n);
     return HADES252_OK;
 }
 static int launch_merkle4_level_fast(const uint8_t *children, uint8_t *parents, size_t n, Fr tag, int out_idx,

@@ -1,0 +1,125 @@
+// hades252.hpp -- C++ host-side mirror of the reference's operator interface, over the C ABI.
+//
+// The reference is compiled code (Rust) and this image has no Rust toolchain, so the host side
+// above the C ABI is written in C++.  Names, argument meaning and failure behaviour follow
+//   pub trait Strategy<T>           reference src/strategies.rs:31-163
+//   pub struct ScalarStrategy       reference src/strategies/scalar.rs:11-50
+//   WIDTH / TOTAL_FULL_ROUNDS / PARTIAL_ROUNDS   reference src/lib.rs:20-27
+// batched: where the reference takes `&mut [BlsScalar]` of exactly WIDTH words, these methods take
+// any whole number of WIDTH-word states and apply the operation to each, in place.
+// Header-only; link with -lhades252 (and the HIP runtime for device buffers).
+#ifndef HADES252_HPP
+#define HADES252_HPP
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#include "hades252.h"
+
+namespace dusk_hades {
+
+constexpr std::size_t WIDTH = HADES252_WIDTH;                          // src/lib.rs:27
+constexpr std::size_t TOTAL_FULL_ROUNDS = HADES252_TOTAL_FULL_ROUNDS;  // src/lib.rs:21
+constexpr std::size_t PARTIAL_ROUNDS = HADES252_PARTIAL_ROUNDS;        // src/lib.rs:25
+
+// In-memory BlsScalar of dusk-bls12_381: 4 x u64 little-endian Montgomery limbs.
+struct BlsScalar {
+    std::uint64_t limbs[4];
+};
+static_assert(sizeof(BlsScalar) == 32, "BlsScalar must be 32 bytes");
+
+// The reference panics (and aborts: Cargo.toml:20); the mirror throws.
+struct HadesPanic : std::runtime_error {
+    int code;
+    HadesPanic(const std::string &what, int c) : std::runtime_error(what), code(c) {}
+};
+
+inline void check(int rc, const char *where) {
+    if (rc != HADES252_OK)
+        throw HadesPanic(std::string(where) + ": " + hades252_strerror(rc), rc);
+}
+
+// `ROUND_CONSTANTS.iter()` (src/strategies.rs:141): a cursor into the device-resident table.
+struct RoundConstantsIter {
+    std::size_t pos = 0;
+    static constexpr std::size_t CONSTANTS = 960;          // src/round_constants.rs:18
+};
+
+// A device-resident batch of states (caller-owned memory on the current HIP device).
+struct DeviceStates {
+    void *ptr;
+    std::size_t n_states;
+    void *stream;   // hipStream_t, nullptr = default stream
+};
+
+template <typename T>
+class Strategy {
+public:
+    virtual ~Strategy() = default;
+
+    // src/strategies.rs:33-41
+    static std::size_t next_c(RoundConstantsIter &constants) {
+        if (constants.pos >= RoundConstantsIter::CONSTANTS) throw HadesPanic("Hades252 out of ARK constants", -1);
+        return constants.pos++;
+    }
+    virtual void add_round_key(RoundConstantsIter &constants, T words) = 0;   // src/strategies.rs:50-52
+    virtual void quintic_s_box(T value) = 0;                                  // src/strategies.rs:59
+    virtual void mul_matrix(RoundConstantsIter &constants, T values) = 0;     // src/strategies.rs:63-65
+    virtual void apply_partial_round(RoundConstantsIter &constants, T words) = 0;   // :79-93
+    virtual void apply_full_round(RoundConstantsIter &constants, T words) = 0;      // :107-119
+    virtual void perm(T data) = 0;                                                  // :140-157
+    static std::size_t rounds() { return TOTAL_FULL_ROUNDS + PARTIAL_ROUNDS; }      // :160-162
+};
+
+// GPU-backed ScalarStrategy.  Stateless like the reference's zero-sized struct.
+class ScalarStrategy : public Strategy<DeviceStates> {
+    static int round_of(RoundConstantsIter &c, const char *where) {
+        if (c.pos % WIDTH != 0) throw HadesPanic(std::string(where) + ": cursor not at a round boundary", -1);
+        if (c.pos / WIDTH >= rounds()) throw HadesPanic("Hades252 out of ARK constants", -1);
+        return static_cast<int>(c.pos / WIDTH);
+    }
+    static void advance(RoundConstantsIter &c) {
+        for (std::size_t i = 0; i < WIDTH; i++) next_c(c);
+    }
+
+public:
+    static ScalarStrategy new_() { return ScalarStrategy(); }   // src/strategies/scalar.rs:17-19
+
+    void add_round_key(RoundConstantsIter &constants, DeviceStates w) override {   // scalar.rs:23-30
+        check(hades252_add_round_key_dev(w.ptr, w.n_states, round_of(constants, "add_round_key"), w.stream),
+              "add_round_key");
+        advance(constants);
+    }
+    // every 32-byte scalar of the batch (n_states counts scalars here)
+    void quintic_s_box(DeviceStates v) override {                                   // scalar.rs:32-34
+        check(hades252_quintic_s_box_dev(v.ptr, v.n_states, v.stream), "quintic_s_box");
+    }
+    void mul_matrix(RoundConstantsIter &, DeviceStates v) override {                // scalar.rs:36-49
+        check(hades252_mul_matrix_dev(v.ptr, v.n_states, v.stream), "mul_matrix");
+    }
+    void apply_partial_round(RoundConstantsIter &constants, DeviceStates w) override {
+        check(hades252_apply_partial_round_dev(w.ptr, w.n_states, round_of(constants, "apply_partial_round"), w.stream),
+              "apply_partial_round");
+        advance(constants);
+    }
+    void apply_full_round(RoundConstantsIter &constants, DeviceStates w) override {
+        check(hades252_apply_full_round_dev(w.ptr, w.n_states, round_of(constants, "apply_full_round"), w.stream),
+              "apply_full_round");
+        advance(constants);
+    }
+    void perm(DeviceStates data) override {
+        check(hades252_perm_batch_dev(data.ptr, data.n_states, data.stream), "perm");
+    }
+
+    // `strategy.perm(&mut state)` on host memory: len must be a multiple of WIDTH
+    // (the reference panics for len != WIDTH, scalar.rs:48).
+    void perm(BlsScalar *data, std::size_t len) {
+        if (len % WIDTH != 0) throw HadesPanic("perm: slice length is not a multiple of WIDTH", -1);
+        check(hades252_perm_batch(reinterpret_cast<std::uint64_t *>(data), len / WIDTH), "perm");
+    }
+};
+
+}  // namespace dusk_hades
+#endif

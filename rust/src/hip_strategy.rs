@@ -1,0 +1,126 @@
+//! `HipStrategy` -- batched, GPU-backed implementor of `dusk_hades::Strategy<BlsScalar>`.
+//!
+//! SOURCE ONLY: this image has no Rust toolchain, so this file has never been compiled here.
+//! It is the binding a maintainer of dusk-hades would add; everything it
+//! calls is exercised from C++ and Python through the same C ABI (`include/hades252.h`).
+//!
+//! Intended location in the reference tree: `src/strategies/hip.rs`, gated behind a cargo
+//! feature `hip` (pattern of the existing `plonk` feature, Cargo.toml:25-26, src/lib.rs:29-30,
+//! src/strategies.rs:20-21), because the crate is `#![no_std]` (src/lib.rs:8) and linking a
+//! shared library needs `std`.
+//!
+//! Behaviour: `perm(&mut data)` permutes every WIDTH-sized chunk of `data` in place
+//! (`data.len() == WIDTH` is exactly `ScalarStrategy::perm`); a length that is not a multiple
+//! of WIDTH panics, like `copy_from_slice` does in the reference (src/strategies/scalar.rs:48);
+//! any error from the library panics (release builds abort: Cargo.toml:20), nothing unwinds
+//! through the FFI.
+
+use super::{ScalarStrategy, Strategy};
+use crate::WIDTH;
+use dusk_bls12_381::BlsScalar;
+
+#[link(name = "hades252")]
+extern "C" {
+    /// include/hades252.h: in place on host memory, `n_perms * 5 * 4` u64 Montgomery limbs.
+    fn hades252_perm_batch(states: *mut u64, n_perms: usize) -> i32;
+    /// include/hades252.h: shards the batch over the node's GPUs (0 = all), no collective.
+    fn hades252_perm_batch_multi(states: *mut u64, n_perms: usize, n_devices: i32) -> i32;
+    fn hades252_strerror(code: i32) -> *const core::ffi::c_char;
+}
+
+/// Batched Hades252 strategy on MI355X.  Zero-sized and stateless like `ScalarStrategy`
+/// (src/strategies/scalar.rs:11-13); the library is re-entrant, so strategies on different
+/// threads may run concurrently.
+#[derive(Default)]
+pub struct HipStrategy {
+    /// 0 = current device only; n > 0 = shard host batches over the first n GPUs.
+    pub devices: i32,
+}
+
+impl HipStrategy {
+    /// Constructs a new `HipStrategy` (mirrors `ScalarStrategy::new`, scalar.rs:17-19).
+    pub fn new() -> Self {
+        Default::default()
+    }
+
+    fn check(rc: i32) {
+        if rc != 0 {
+            let msg = unsafe { core::ffi::CStr::from_ptr(hades252_strerror(rc)) };
+            panic!("libhades252: {:?} ({})", msg, rc);
+        }
+    }
+}
+
+// `BlsScalar` is `#[repr(transparent)]`-like over `[u64; 4]` (4 x u64 little-endian Montgomery
+// limbs: `internal_repr()`, assets/HOWTO.md:45-47; `from_raw([u64; 4])`, round_constants.rs:41).
+// The cast below relies on that layout; the `_bytes` entry point of the library is the
+// layout-independent alternative (`to_bytes()` / `from_bytes()`).
+const _: () = assert!(core::mem::size_of::<BlsScalar>() == 32);
+
+impl Strategy<BlsScalar> for HipStrategy {
+    // The three per-operation methods are never on the batched path; they keep the reference's
+    // semantics by delegating to the scalar implementation (src/strategies/scalar.rs:23-49).
+    fn add_round_key<'b, I>(&mut self, constants: &mut I, words: &mut [BlsScalar])
+    where
+        I: Iterator<Item = &'b BlsScalar>,
+    {
+        ScalarStrategy::new().add_round_key(constants, words)
+    }
+
+    fn quintic_s_box(&mut self, value: &mut BlsScalar) {
+        ScalarStrategy::new().quintic_s_box(value)
+    }
+
+    fn mul_matrix<'b, I>(&mut self, constants: &mut I, values: &mut [BlsScalar])
+    where
+        I: Iterator<Item = &'b BlsScalar>,
+    {
+        ScalarStrategy::new().mul_matrix(constants, values)
+    }
+
+    /// Overrides the provided `perm` (src/strategies.rs:140-157): all 67 rounds of every state
+    /// run in one GPU kernel.
+    fn perm(&mut self, data: &mut [BlsScalar]) {
+        assert!(
+            data.len() % WIDTH == 0,
+            "Hades252 state length must be a multiple of WIDTH"
+        );
+        let n_perms = data.len() / WIDTH;
+        let ptr = data.as_mut_ptr() as *mut u64;
+        let rc = unsafe {
+            if self.devices > 0 {
+                hades252_perm_batch_multi(ptr, n_perms, self.devices)
+            } else {
+                hades252_perm_batch(ptr, n_perms)
+            }
+        };
+        Self::check(rc);
+    }
+}
+
+#[cfg(test)]
+mod tests {
+    use super::*;
+
+    // Mirrors hades_det (src/strategies/scalar.rs:62-74) and adds the cross-check the
+    // reference uses between its two strategies (src/strategies/gadget.rs:166-175).
+    #[test]
+    fn hip_matches_scalar() {
+        let mut a = [BlsScalar::from(17u64); WIDTH];
+        let mut b = a;
+        ScalarStrategy::new().perm(&mut a);
+        HipStrategy::new().perm(&mut b);
+        assert_eq!(a, b);
+    }
+
+    #[test]
+    fn hip_batch_matches_scalar() {
+        let mut batch: Vec<BlsScalar> = (0..5 * 1000u64).map(BlsScalar::from).collect();
+        let mut expect = batch.clone();
+        for chunk in expect.chunks_mut(WIDTH) {
+            ScalarStrategy::new().perm(chunk);
+        }
+        HipStrategy::new().perm(&mut batch);
+        assert_eq!(batch, expect);
+    }
+}

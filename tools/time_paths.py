@@ -1,0 +1,46 @@
+"""Development / DESIGN.md numbers: host-pointer (PCIe-inclusive) rate, Merkle tree build time,
+literal-vs-fast kernel, per-size throughput."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from hades252_amd import strategy as H, _lib
+
+dev = torch.device("cuda", 0)
+
+def timed(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+print("== device-resident kernels")
+for logn in (10, 14, 16, 18, 20, 22, 24, 26):
+    n = 1 << logn
+    buf = H.gen_b(5 * n, dev)
+    for k, name in ((2, "fast"), (1, "literal")):
+        if k == 1 and logn > 24: continue
+        s = H.ScalarStrategy(k)
+        dt = timed(lambda: s.perm(buf), reps=3 if logn > 20 else 10)
+        print("n=2^%-2d %-8s %9.3f ms  %8.2f Mperm/s  %7.2f GB/s algorithmic" % (logn, name, dt * 1e3, n / dt / 1e6, 320 * n / dt / 1e9))
+    del buf
+
+print("== host-pointer path (hades252_perm_batch: H2D + kernel + D2H, pageable numpy memory)")
+for logn in (16, 20, 22):
+    n = 1 << logn
+    host = H.gen_b(5 * n, dev).cpu().numpy().view(np.uint64).reshape(-1).copy()
+    s = H.ScalarStrategy()
+    dt = timed(lambda: s.perm(host), reps=2)
+    print("n=2^%-2d host path %9.3f ms  %8.2f Mperm/s (%.2f GB/s over PCIe each way)" % (logn, dt * 1e3, n / dt / 1e6, 160 * n / dt / 1e9))
+
+print("== Merkle arity-4 (tag 15, out word 1), level by level")
+tag = 15 * ((1 << 256) % 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001) % 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+for logn in (16, 20, 24):
+    n = 1 << logn
+    leaves = H.gen_b(n, dev)
+    scratch = torch.empty(_lib.lib().hades252_merkle4_scratch_bytes(n) // 8, dtype=torch.int64, device=dev)
+    dt = timed(lambda: H.merkle4_root(leaves, tag, 1, scratch), reps=3)
+    nodes = (n - 1) // 3
+    root = H.merkle4_root(leaves, tag, 1, scratch).cpu().numpy().view(np.uint64)
+    print("leaves=2^%-2d %9.3f ms  %d perms  %8.2f Mperm/s  root %s" % (logn, dt * 1e3, nodes, nodes / dt / 1e6, "".join("%016x" % int(x) for x in root[::-1])))
