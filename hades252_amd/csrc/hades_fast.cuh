@@ -51,8 +51,18 @@ struct FastTables {
 
 // One limb product accumulated in place; hipcc selects a single v_mad_u64_u32 for this shape
 // as long as both factors are provably 32-bit (see limb_fence).
-__device__ __forceinline__ void mac(uint64_t &acc, uint32_t a, uint32_t b) { acc += (uint64_t)a * b; }
-__device__ __forceinline__ void mac_s(uint64_t &acc, uint32_t a, uint32_t b_uniform) { acc += (uint64_t)a * b_uniform; }
+// The trailing input-only asm gives every partial sum a second use, which stops LLVM's
+// reassociation from rebuilding the column as (p1 + p2 + ...) + carry -- that form needs a fresh
+// chain from zero and an extra 64-bit add per column.  It emits no instruction.
+__device__ __forceinline__ void pin(const uint64_t &acc) { asm volatile("" ::"v"((uint32_t)acc)); }
+__device__ __forceinline__ void mac(uint64_t &acc, uint32_t a, uint32_t b) {
+    acc += (uint64_t)a * b;
+    pin(acc);
+}
+__device__ __forceinline__ void mac_s(uint64_t &acc, uint32_t a, uint32_t b_uniform) {
+    acc += (uint64_t)a * b_uniform;
+    pin(acc);
+}
 
 // Zero-instruction fence on one limb: makes the value an opaque 32-bit VGPR.  Without it hipcc
 // carries limbs across the round loop's back-edge as 64-bit values (zext(trunc(acc) & mask) is
@@ -185,33 +195,41 @@ __device__ __forceinline__ void add_lazy(F29 &x, const F29 &c) {
     for (int k = 0; k < kNL; k++) x.l[k] += c.l[k];
 }
 
-// Row i of Y = C * X followed by a one-limb Montgomery step and carry normalisation, again on a
-// single accumulator: returns (Y_i + m p) / 2^29 with limbs < 2^29.
+// Y = C * X followed by a one-limb Montgomery step and carry normalisation of every row:
+// st[i] <- (Y_i + m_i p) / 2^29 with limbs < 2^29.  Limb-major: five accumulators (one per output
+// row) walk the limbs together, so input limb k of all five words dies at step k and output limb
+// k-1 takes its place -- the layer needs ~15 registers beyond the state itself (row-major needs a
+// second copy of the state).
 // Input limbs < 2^30, C < 2^17: columns < 2^50 + 2^58; Y_i < 2^275 => result < 2^256.
-template <int I>
-__device__ __forceinline__ F29 small_mds_row(const F29 (&st)[5]) {
-    uint64_t acc = 0;
+__device__ __forceinline__ void small_mds(F29 (&st)[5]) {
+    uint64_t acc[5];
+    uint32_t m[5];
+    uint32_t x[5];
 #pragma unroll
-    for (int j = 0; j < 5; j++) mac_s(acc, st[j].l[0], MDS_SMALL[I][j]);
-    const uint32_t m = (0u - (uint32_t)acc) & kMask29;
-    acc = (acc + kMask29) >> kLB;
-    F29 r;
+    for (int j = 0; j < 5; j++) x[j] = st[j].l[0];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        acc[i] = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) mac_s(acc[i], x[j], MDS_SMALL[i][j]);
+        m[i] = (0u - (uint32_t)acc[i]) & kMask29;
+        acc[i] = (acc[i] + kMask29) >> kLB;
+    }
 #pragma unroll
     for (int k = 1; k < kNL; k++) {
 #pragma unroll
-        for (int j = 0; j < 5; j++) mac_s(acc, st[j].l[k], MDS_SMALL[I][j]);
-        mac_s(acc, m, P29[k]);
-        r.l[k - 1] = (uint32_t)acc & kMask29;
-        acc >>= kLB;
+        for (int j = 0; j < 5; j++) x[j] = st[j].l[k];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+#pragma unroll
+            for (int j = 0; j < 5; j++) mac_s(acc[i], x[j], MDS_SMALL[i][j]);
+            mac_s(acc[i], m[i], P29[k]);
+            st[i].l[k - 1] = (uint32_t)acc[i] & kMask29;
+            acc[i] >>= kLB;
+        }
     }
-    r.l[kNL - 1] = (uint32_t)acc;
-    return r;
-}
-
-__device__ __forceinline__ void small_mds(F29 (&st)[5]) {
-    F29 o0 = small_mds_row<0>(st), o1 = small_mds_row<1>(st), o2 = small_mds_row<2>(st),
-        o3 = small_mds_row<3>(st), o4 = small_mds_row<4>(st);
-    st[0] = o0; st[1] = o1; st[2] = o2; st[3] = o3; st[4] = o4;
+#pragma unroll
+    for (int i = 0; i < 5; i++) st[i].l[kNL - 1] = (uint32_t)acc[i];
 }
 
 // One round.  ARK touches all five words in both round kinds (reference src/strategies.rs:86,
