@@ -18,23 +18,29 @@ P = D.P
 LB, NL = D.LIMB_BITS, D.NLIMB
 MASK = (1 << LB) - 1
 P29 = D.to_limbs29(P)
-U64 = 1 << 64
-U32 = 1 << 32
+I63 = 1 << 63
+I31 = 1 << 31
+LAZY = 3 << 28          # |limb| < 1.5 * 2^29 after the balanced-limb ARK
 
 
 def val(limbs):
     return sum(l << (LB * k) for k, l in enumerate(limbs))
 
 
+def check_acc(acc):
+    assert -I63 <= acc < I63, "signed 64-bit accumulator overflow"
+
+
 def mont_fips(a, b, sqr=False):
-    """mont_fips<SQR> of hades_fast.cuh: returns limbs of a*b/2^261 (mod p), value < 2^256."""
-    assert all(0 <= x < (1 << 30) for x in a + b), "input limbs must be < 2^30"
-    assert val(a) < (1 << 258) and val(b) < (1 << 258)
+    """mont_fips of hades_fast.cuh (signed digits): normalised limbs of a value
+    == a*b/2^261 (mod p) in (a*b/Rp - p, a*b/Rp]."""
+    assert all(-LAZY < x < LAZY for x in a + b), "|input limb| must be < 1.5 * 2^29"
+    assert abs(val(a)) < (1 << 257) and abs(val(b)) < (1 << 257)
     m = [0] * NL
     r = [0] * NL
     acc = 0
-    d = [(x << 1) for x in a]
-    assert all(x < U32 for x in d)
+    d = [2 * x for x in a]
+    assert all(-I31 <= x < I31 for x in d)
     for k in range(2 * NL - 1):
         lo, hi = (0, k) if k < NL else (k - NL + 1, NL - 1)
         for i in range(lo, hi + 1):
@@ -46,49 +52,58 @@ def mont_fips(a, b, sqr=False):
                     acc += a[i] * a[i]
             else:
                 acc += a[i] * b[j]
-            assert acc < U64
+            check_acc(acc)
         for i in range(lo, hi + 1):
             if k - i >= 1:
-                acc += m[i] * P29[k - i]
-                assert acc < U64
+                acc -= m[i] * P29[k - i]
+                check_acc(acc)
+        low = acc & MASK                     # two's complement low bits, in [0, 2^29)
         if k < NL:
-            m[k] = (-acc) & MASK
-            assert (acc + m[k]) & MASK == 0
-            assert acc + MASK < U64
-            assert (acc + MASK) >> LB == (acc + m[k]) >> LB
-            acc = (acc + MASK) >> LB
+            m[k] = low
+            assert (acc - low) % (1 << LB) == 0
         else:
-            r[k - NL] = acc & MASK
-            acc >>= LB
-    assert acc < U32
+            r[k - NL] = low
+        acc >>= LB                           # arithmetic shift (python ints floor)
+    assert -I31 <= acc < I31
     r[NL - 1] = acc
+    v = val(r)
+    ab = val(a) * val(b)
+    assert ab - P * (1 << (LB * NL)) < v * (1 << (LB * NL)) <= ab, "result outside (ab/Rp - p, ab/Rp]"
     return r
 
 
-def small_mds_row(st, i):
-    acc = 0
-    for j in range(5):
-        acc += st[j][0] * D.MDS_SMALL[i][j]
-    assert acc < U64
-    m = (-acc) & MASK
-    acc = (acc + MASK) >> LB
-    r = [0] * NL
-    for k in range(1, NL):
+def small_mds(st):
+    acc = [0] * 5
+    m = [0] * 5
+    out = [[0] * NL for _ in range(5)]
+    for i in range(5):
         for j in range(5):
-            acc += st[j][k] * D.MDS_SMALL[i][j]
-        acc += m * P29[k]
-        assert acc < (1 << 60)
-        r[k - 1] = acc & MASK
-        acc >>= LB
-    assert acc < U32
-    r[NL - 1] = acc
-    return r
+            acc[i] += st[j][0] * D.MDS_SMALL[i][j]
+        check_acc(acc[i])
+        m[i] = acc[i] & MASK
+        acc[i] >>= LB
+    for k in range(1, NL):
+        for i in range(5):
+            for j in range(5):
+                acc[i] += st[j][k] * D.MDS_SMALL[i][j]
+            acc[i] -= m[i] * P29[k]
+            assert abs(acc[i]) < (1 << 60)
+            out[i][k - 1] = acc[i] & MASK
+            acc[i] >>= LB
+    for i in range(5):
+        assert -I31 <= acc[i] < I31
+        out[i][NL - 1] = acc[i]
+    return out
 
 
 def sbox(x):
     x2 = mont_fips(x, x, True)
     x4 = mont_fips(x2, x2, True)
     return mont_fips(x4, x)
+
+
+def normalised(x):
+    return all(0 <= l < (1 << LB) for l in x[:-1]) and abs(val(x)) < (1 << 256)
 
 
 def fast_perm_model(mont_vals):
@@ -99,20 +114,27 @@ def fast_perm_model(mont_vals):
         full = D.is_full_round(r)
         a, k = (sch["full"][r], None) if full else sch["part"][r]
         for w in range(5):
-            st[w] = [x + y for x, y in zip(st[w], D.to_limbs29(a[w]))]     # lazy ARK, limbs < 2^30
+            st[w] = [x + y for x, y in zip(st[w], D.to_balanced29(a[w]))]     # lazy ARK
+            assert all(-LAZY < l < LAZY for l in st[w])
         if full:
             st = [sbox(x) for x in st]
         else:
             st[4] = mont_fips(sbox(st[4]), D.to_limbs29(k))
-        st = [small_mds_row(st, i) for i in range(5)]
+        st = small_mds(st)
         for x in st:
-            assert all(l < (1 << LB) for l in x) and val(x) < (1 << 256)
+            assert normalised(x)
     f = D.to_limbs29(sch["final_f"])
     out = []
     for x in st:
         v = val(mont_fips(x, f))
-        assert v < 2 * P            # one conditional subtraction suffices
-        out.append(v - P if v >= P else v)
+        assert -2 * P < v < P
+        v += 2 * P                       # finalize(): + 2p, then two conditional subtractions
+        assert 0 < v < 3 * P and v < (1 << 256)
+        for _ in range(2):
+            if v >= P:
+                v -= P
+        assert 0 <= v < P
+        out.append(v)
     return out
 
 
@@ -130,23 +152,36 @@ def test_model_matches_spec_oracle():
 
 
 def test_product_bounds_adversarial():
-    """All limbs at the lazy maximum 2^30 - 1 except the top ones (value < 2^258): no column overflow."""
-    big = [(1 << 30) - 1] * (NL - 1) + [(1 << 25) - 1]
-    assert val(big) < (1 << 258)
-    for sq in (False, True):
-        r = mont_fips(big, big, sq)
-        assert val(r) < (1 << 256)
-        assert val(r) % P == val(big) * val(big) * pow(1 << (LB * NL), -1, P) % P
+    """Operand limbs at the lazy extremes (positive and mixed-sign): no signed 64-bit overflow."""
+    hi_limb = LAZY - 1
+    for pattern in ([hi_limb] * (NL - 1) + [(1 << 24) - 1],
+                    [hi_limb, -(1 << 28)] * 4 + [-(1 << 24)],
+                    [-(1 << 28)] * (NL - 1) + [(1 << 24)]):
+        assert abs(val(pattern)) < (1 << 257)
+        for sq in (False, True):
+            r = mont_fips(pattern, pattern, sq)
+            assert normalised(r)
+            assert val(r) % P == val(pattern) * val(pattern) * pow(1 << (LB * NL), -1, P) % P
 
 
 def test_linear_layer_bounds_adversarial():
-    big = [(1 << 30) - 1] * (NL - 1) + [(1 << 24) - 1]      # value < 2^256
-    st = [big] * 5
-    for i in range(5):
-        r = small_mds_row(st, i)
-        y = sum(D.MDS_SMALL[i][j] for j in range(5)) * val(big)
-        assert val(r) < (1 << 256)
-        assert val(r) % P == y * pow(1 << LB, -1, P) % P
+    big = [LAZY - 1] * (NL - 1) + [(1 << 24) - 1]
+    neg = [-(1 << 28)] * (NL - 1) + [-(1 << 24)]
+    for st in ([big] * 5, [neg] * 5, [big, neg, big, neg, big]):
+        out = small_mds(st)
+        for i in range(5):
+            y = sum(D.MDS_SMALL[i][j] * val(st[j]) for j in range(5))
+            assert normalised(out[i])
+            assert val(out[i]) % P == y * pow(1 << LB, -1, P) % P
+
+
+def test_balanced_constants():
+    sch = D.fast_schedule()
+    for r in range(D.ROUNDS):
+        a = sch["full"][r] if r in sch["full"] else sch["part"][r][0]
+        for v in a:
+            limbs = D.to_balanced29(v)
+            assert val(limbs) == v and all(-(1 << 28) <= l < (1 << 28) for l in limbs[:-1])
 
 
 def test_schedule_tables_shape():

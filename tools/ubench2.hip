@@ -47,12 +47,12 @@ __global__ void k_sustained(uint32_t *out, Stamp *st, int iters, uint32_t seed) 
 }
 
 // building blocks: KIND 0 = mont_mul chain, 1 = mont_sqr chain, 2 = sbox chain, 3 = small_mds, 4 = const mul
-__device__ const uint32_t d_k[16] = {0x12345678 & 0x1fffffff, 0x0abcdef1, 0x1fedcba9, 0x13572468, 0x02468ace, 0x1badf00d, 0x0c0ffee0, 0x1eadbeef & 0x1fffffff, 0x123456};
+__device__ const int32_t d_k[16] = {0x12345678 & 0x1fffffff, 0x0abcdef1, 0x1fedcba9, 0x13572468, 0x02468ace, 0x1badf00d, 0x0c0ffee0, 0x1eadbeef & 0x1fffffff, 0x123456};
 template <int KIND, int MINW>
 __global__ void __launch_bounds__(256, MINW) k_blocks(uint32_t *out, Stamp *stamps, int iters, uint32_t seed) {
     F29 st[5];
     for (int w = 0; w < 5; w++)
-        for (int k = 0; k < kNL; k++) st[w].l[k] = (seed * (w * 9 + k + 1) * 2654435761u + threadIdx.x * 40503u) & kMask29;
+        for (int k = 0; k < kNL; k++) st[w].l[k] = (int32_t)((seed * (w * 9 + k + 1) * 2654435761u + threadIdx.x * 40503u) & kMask29);
     unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll 1
     for (int it = 0; it < iters; it++) {
