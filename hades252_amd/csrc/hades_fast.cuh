@@ -202,12 +202,17 @@ __device__ __forceinline__ void small_mds(F29 (&st)[5]) {
     for (int i = 0; i < 5; i++) st[i].l[kNL - 1] = (int32_t)acc[i];
 }
 
-// One round.  ARK touches all five words in both round kinds (reference src/strategies.rs:86,
-// :111); full rounds S-box every word, partial rounds the last word only, which then takes the
-// rescale product.  `full` is wave-uniform, so the branches are scalar.
+// One round.  The reference adds round keys to all five words in both round kinds
+// (src/strategies.rs:86, :111); full rounds S-box every word, partial rounds the last word only,
+// which then takes the rescale product.  `full` is wave-uniform, so the branches are scalar.
 __device__ __forceinline__ void fast_round(const int32_t *rec, bool full, F29 (&st)[5]) {
+    // partial rounds: the constants of words 0..3 were pushed through the linear layers on the
+    // host (hades252_amd/_derive.py), only word 4 receives one
+    if (full) {
 #pragma unroll
-    for (int w = 0; w < 5; w++) add_lazy(st[w], rec + w * kNL);
+        for (int w = 0; w < 4; w++) add_lazy(st[w], rec + w * kNL);
+    }
+    add_lazy(st[4], rec + 4 * kNL);
     if (full) {
         st[0] = sbox29(st[0]);
         st[1] = sbox29(st[1]);
