@@ -32,6 +32,7 @@ SIGNATURES = {
     "hades252_perm_batch_dev": (c_int, [c_void_p, c_size_t, c_void_p]),
     "hades252_perm_batch_dev_ex": (c_int, [c_void_p, c_size_t, c_void_p, c_int]),
     "hades252_perm_batch_multi": (c_int, [c_void_p, c_size_t, c_int]),
+    "hades252_perm_trace_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "hades252_add_round_key_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
     "hades252_quintic_s_box_dev": (c_int, [c_void_p, c_size_t, c_void_p]),
     "hades252_mul_matrix_dev": (c_int, [c_void_p, c_size_t, c_void_p]),

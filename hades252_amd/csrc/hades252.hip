@@ -61,6 +61,26 @@ __global__ void __launch_bounds__(kBlock) k_states_literal(uint8_t *__restrict__
     wave_store_records<5>(states, rec0, n, slab, st);
 }
 
+// Per-round trace: the state after every round (what the PLONK gadget needs as witnesses,
+// reference src/strategies/gadget.rs:41-133), round-major: trace[r] is a whole AoS batch.
+__global__ void __launch_bounds__(kBlock) k_perm_trace_literal(const uint8_t *__restrict__ states,
+                                                               uint8_t *__restrict__ trace, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<5>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr st[5];
+    wave_load_records<5>(states, rec0, n, slab, st);
+    LiteralView V{d_ark_mont, d_mds_mont};
+#pragma unroll 1
+    for (int r = 0; r < 67; r++) {
+        if (r < 4 || r >= 63)
+            lit_full_round(V, r, st);
+        else
+            lit_partial_round(V, r, st);
+        wave_store_records<5>(trace + (size_t)r * n * 160, rec0, n, slab, st);
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) k_sbox(uint8_t *__restrict__ scalars, size_t n) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *slab = wave_slab<1>(lds);
@@ -434,6 +454,15 @@ int hades252_perm_batch_multi(uint64_t *states, size_t n_perms, int n_devices) {
             tl_last_hip_error = hip_errs[g];
             return rcs[g];
         }
+    return HADES252_OK;
+}
+
+int hades252_perm_trace_dev(const void *d_states, void *d_trace, size_t n_perms, void *stream) {
+    if (n_perms == 0) return HADES252_OK;
+    if (d_states == nullptr || d_trace == nullptr || n_perms > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_perm_trace_literal, dim3(blocks_for(n_perms)), dim3(kBlock), lds_for(5), (hipStream_t)stream,
+                       (const uint8_t *)d_states, (uint8_t *)d_trace, n_perms);
+    HIP_TRY(hipGetLastError());
     return HADES252_OK;
 }
 

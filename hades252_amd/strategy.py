@@ -208,6 +208,18 @@ class ScalarStrategy(Strategy):
             self.apply_full_round(constants, data)
 
 
+def perm_trace(states_t):
+    """State after every round (round-major: result[r] is the batch after round r); the input is
+    left untouched.  Witness pre-computation for the reference's GadgetStrategy
+    (src/strategies/gadget.rs:41-133)."""
+    import torch
+    ptr, n, dev = _dev_buffer(states_t, STATE_BYTES, "perm_trace")
+    trace = torch.empty((Strategy.rounds(), n, WIDTH, 4), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_perm_trace_dev(ptr, trace.data_ptr(), n, _stream_ptr(dev)), "perm_trace")
+    return trace
+
+
 # ---- helpers around the strategy (wire format, Merkle, synthetic data) ----------------------
 def from_bytes(bytes_t, out_t=None):
     """``BlsScalar::from_bytes`` on device: 32-byte canonical LE -> Montgomery limbs.

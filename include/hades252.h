@@ -76,6 +76,12 @@ int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int
  * stream per device, no collective).  n_devices <= 0 means all visible devices. */
 int hades252_perm_batch_multi(uint64_t *states, size_t n_perms, int n_devices);
 
+/* Per-round trace (witness pre-computation for GadgetStrategy, src/strategies/gadget.rs:41-133):
+ * d_trace receives 67 batches, round-major: trace[r] (n_perms x 160 B, same AoS format) is the
+ * state of every permutation after round r's mul_matrix; trace[66] equals the perm output.
+ * d_states is not modified.  Needs 67 * 160 * n_perms bytes. */
+int hades252_perm_trace_dev(const void *d_states, void *d_trace, size_t n_perms, void *stream);
+
 /* ---- the trait's per-operation methods, batched on device ------------------------------- */
 /* Strategy::add_round_key (src/strategies/scalar.rs:23-30) with the cursor at 5*round:
  * word w of every state += ROUND_CONSTANTS[5*round + w].  0 <= round < 67. */

@@ -296,3 +296,87 @@ def test_generators_and_digest(torch_cuda, H, oracle):
     cut = 4 * 5003
     d1, d2 = H.digest(flat[:cut], 0), H.digest(flat[cut:], cut)
     assert [(x + y) & 0xFFFFFFFFFFFFFFFF for x, y in zip(d1, d2)] == H.digest(b)
+
+
+# ---- BASELINE full sizes: size-independent properties ----------------------------------------
+def test_config3_2pow26_properties(torch_cuda, hades_lib, H, oracle):
+    """BASELINE config[2]: 2^26 permutations on one GPU.  The oracle cannot replay 2^26, so:
+    (1) a strided sample (every 2^14-th state, 4096 states) is compared bit for bit with the oracle,
+    (2) the two independent device implementations agree on the digest of ALL outputs,
+    (3) one call == two ragged calls (no cross-lane / cross-launch state)."""
+    torch = torch_cuda
+    n = 1 << 26
+    a = H.gen_b(5 * n, "cuda")
+    stride = 1 << 14
+    sample_in = a.view(n, 20)[::stride].contiguous()
+    host_in = to_host(sample_in).copy()
+    assert (host_in[:20] == oracle.gen_b(0, 5)).all()
+    H.ScalarStrategy(2).perm(a)
+    got = to_host(a.view(n, 20)[::stride].contiguous())
+    assert (got == oracle.perm_batch(host_in)).all()
+    d_fast = H.digest(a)
+    # literal kernel on the same inputs
+    H.gen_b(5 * n, "cuda", out=a.view(-1, 4))
+    H.ScalarStrategy(1).perm(a)
+    assert H.digest(a) == d_fast
+    # split invariance with the shipped kernel
+    H.gen_b(5 * n, "cuda", out=a.view(-1, 4))
+    flat = a.view(-1)
+    cut = 20 * ((n // 3) + 7)
+    H.ScalarStrategy(2).perm(flat[:cut])
+    H.ScalarStrategy(2).perm(flat[cut:])
+    assert H.digest(a) == d_fast
+
+
+def test_config4_merkle_2pow24(torch_cuda, H, oracle):
+    """BASELINE config[3]: arity-4 tree over 2^24 leaves, level by level (5 592 405 permutations).
+    Property: the root equals the root of the 4 sub-tree roots (the multi-GPU decomposition of
+    SURVEY section 8(e)); a 2^20-leaf sub-tree root is checked against the oracle."""
+    torch = torch_cuda
+    tag = S.to_mont(15)
+    n = 1 << 24
+    leaves = H.gen_b(n, "cuda")
+    root = to_host(H.merkle4_root(leaves, tag, 1))
+    q = n // 4
+    subs = torch.cat([H.merkle4_root(leaves[i * q:(i + 1) * q], tag, 1) for i in range(4)])
+    top = to_host(H.merkle4_level(subs, tag, 1))
+    assert (top == root).all()
+    sub = 1 << 20
+    exp = oracle.merkle4_root(oracle.gen_b(0, sub), tag, 1)
+    assert (to_host(H.merkle4_root(leaves[:sub], tag, 1)) == exp).all()
+
+
+def test_config5_sharding_arithmetic(torch_cuda, H):
+    """BASELINE config[4] decomposition on one device: 8 shards generated and permuted
+    independently (global element offsets as bench.py computes them) combine, by digest
+    addition, to the digest of the unsharded batch."""
+    from hades252_amd import sharding
+    n_total = 1 << 23
+    whole = H.gen_b(5 * n_total, "cuda")
+    H.ScalarStrategy().perm(whole)
+    ref = H.digest(whole)
+    acc = [0, 0, 0, 0]
+    for rank in range(8):
+        b, e = sharding.shard_range(rank, 8, n_total)
+        shard = H.gen_b(5 * (e - b), "cuda", first_elem=5 * b)
+        H.ScalarStrategy().perm(shard)
+        d = H.digest(shard, first_index=20 * b)
+        acc = [(x + y) & 0xFFFFFFFFFFFFFFFF for x, y in zip(acc, d)]
+    assert acc == ref
+
+
+def test_perm_trace(torch_cuda, H, oracle):
+    """Per-round states (Gadget witness pre-computation) vs the oracle's trace."""
+    torch = torch_cuda
+    n = 300
+    inp = oracle.gen_b(777, 5 * n)
+    dev = to_dev(torch, inp)
+    tr = H.perm_trace(dev)
+    assert (to_host(dev) == inp).all()                      # input untouched
+    host = tr.cpu().numpy().view(np.uint64).reshape(67, n, 20)
+    for i in (0, 1, 63, 64, 299):
+        _, otr = oracle.perm_trace(inp[20 * i:20 * i + 20])
+        assert (host[:, i, :] == otr.reshape(67, 20)).all()
+    out = dev.clone()
+    H.ScalarStrategy().perm(out)
+    assert torch.equal(tr[66].reshape(-1), out.reshape(-1))
