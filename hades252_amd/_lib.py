@@ -7,7 +7,8 @@ import os
 from ctypes import c_char_p, c_int, c_size_t, c_uint64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhades252.so")
+# HADES252_LIB overrides the path (development A/B builds only)
+LIB_PATH = os.environ.get("HADES252_LIB") or os.path.join(_HERE, "csrc", "libhades252.so")
 
 OK = 0
 ERR_INVALID_ARG = -1

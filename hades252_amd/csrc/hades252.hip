@@ -151,7 +151,10 @@ __global__ void __launch_bounds__(kBlock) k_merkle4_level_literal(const uint8_t 
 // The shipped hot path: one permutation per lane, scale-tracked formulation (hades_fast.cuh).
 // __launch_bounds__(256, 4): 4 waves per SIMD = at most 128 VGPRs; the kernel needs 108 and does
 // not spill.  (2 waves/SIMD: same speed; 5: spills, 6 % slower; 6: 35 % slower -- measured.)
-__global__ void __launch_bounds__(kBlock, 4) k_perm_fast(uint8_t *__restrict__ states, size_t n) {
+#ifndef HADES_FAST_MINW
+#define HADES_FAST_MINW 4
+#endif
+__global__ void __launch_bounds__(kBlock, HADES_FAST_MINW) k_perm_fast(uint8_t *__restrict__ states, size_t n) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *slab = wave_slab<5>(lds);
     size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
@@ -382,6 +385,40 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
         TRY_CLEAN(hipMemset(d_bad, 0, sizeof(int)));
     }
     uint8_t *h = (uint8_t *)states;
+    // Large batches: page-lock the caller's buffer in place for the duration of the call, so the
+    // chunk copies are true DMA and overlap with the kernels (pageable copies are staged by the
+    // runtime at ~15 GB/s).  If registration is refused (e.g. the range is already registered by
+    // the caller) the pageable path is used; HADES252_HOST_PIN=0 disables the attempt.
+    bool registered = false;
+    static const bool pin_enabled = []() {
+        const char *e = getenv("HADES252_HOST_PIN");
+        return !(e && e[0] == '0');
+    }();
+    if (pin_enabled && n_perms * 160 >= ((size_t)8 << 20)) {
+        if (hipHostRegister(h, n_perms * 160, hipHostRegisterDefault) == hipSuccess)
+            registered = true;
+        else
+            (void)hipGetLastError();
+    }
+    auto cleanup0 = cleanup;
+    auto cleanup_all = [&]() {
+        if (registered) {
+            (void)hipHostUnregister(h);
+            registered = false;
+        }
+        cleanup0();
+    };
+#undef TRY_CLEAN
+#define TRY_CLEAN(expr)                              \
+    do {                                             \
+        hipError_t e_ = (expr);                      \
+        if (e_ != hipSuccess) {                      \
+            tl_last_hip_error = (int)e_;             \
+            (void)hipGetLastError();                 \
+            cleanup_all();                           \
+            return HADES252_ERR_HIP;                 \
+        }                                            \
+    } while (0)
     int k = 0;
     for (size_t off = 0; off < n_perms; off += chunk, k ^= (nbuf - 1)) {
         size_t n = n_perms - off < chunk ? n_perms - off : chunk;
@@ -395,7 +432,7 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
         }
         if (rc != HADES252_OK) {
             for (int i = 0; i < nbuf; i++) (void)hipStreamSynchronize(st[i]);
-            cleanup();
+            cleanup_all();
             return rc;
         }
         if (bytes_format) {
@@ -412,7 +449,7 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
     }
     for (int i = 0; i < nbuf; i++) TRY_CLEAN(hipStreamSynchronize(st[i]));
 #undef TRY_CLEAN
-    cleanup();
+    cleanup_all();
     return result;
 }
 
@@ -420,7 +457,30 @@ int hades252_perm_batch(uint64_t *states, size_t n_perms) {
     return perm_batch_host_on_current_device(states, n_perms, false);
 }
 
+// input validation only (BlsScalar::from_bytes fails for values >= p before anything is computed)
+static bool all_canonical(const uint8_t *bytes, size_t n_scalars) {
+    static const uint64_t kP[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull,
+                                   0x73eda753299d7d48ull};
+    for (size_t i = 0; i < n_scalars; i++) {
+        uint64_t v[4];
+        memcpy(v, bytes + 32 * i, 32);
+        bool less = false;
+        for (int k = 3; k >= 0; k--) {
+            if (v[k] != kP[k]) {
+                less = v[k] < kP[k];
+                break;
+            }
+        }
+        if (!less) return false;
+    }
+    return true;
+}
+
 int hades252_perm_batch_bytes(uint8_t *states, size_t n_perms) {
+    if (n_perms == 0) return HADES252_OK;
+    if (states == nullptr) return HADES252_ERR_INVALID_ARG;
+    // reject the whole batch up front, so a failing call leaves the buffer untouched
+    if (!all_canonical(states, n_perms * 5)) return HADES252_ERR_NOT_CANONICAL;
     return perm_batch_host_on_current_device((uint64_t *)states, n_perms, true);
 }
 

@@ -44,3 +44,11 @@ for logn in (16, 20, 24):
     nodes = (n - 1) // 3
     root = H.merkle4_root(leaves, tag, 1, scratch).cpu().numpy().view(np.uint64)
     print("leaves=2^%-2d %9.3f ms  %d perms  %8.2f Mperm/s  root %s" % (logn, dt * 1e3, nodes, nodes / dt / 1e6, "".join("%016x" % int(x) for x in root[::-1])))
+
+print("== host-pointer path, large batches (in-place page-locking when HADES252_HOST_PIN != 0)")
+for logn in (20, 22, 24):
+    n = 1 << logn
+    host = H.gen_b(5 * n, dev).cpu().numpy().view(np.uint64).reshape(-1).copy()
+    s = H.ScalarStrategy()
+    dt = timed(lambda: s.perm(host), reps=2)
+    print("n=2^%-2d host path %9.3f ms  %8.2f Mperm/s (%.2f GB/s each way)" % (logn, dt * 1e3, n / dt / 1e6, 160 * n / dt / 1e9))
