@@ -34,6 +34,11 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_PERM = 320
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak, MI355X_MICROARCH.md
+# The binding resource is VALU issue.  Static per-permutation instruction counts of k_perm_fast
+# (rocprofv3 SQ_INSTS_VALU / SQ_WAVES agrees) and the chip-wide sustained
+# v_mad_u64_u32 issue rate measured by tools/ubench2.hip (profiles/ubench2_*.txt).
+MADS_PER_PERM = 99 * 387 + 64 * 153 + 67 * 265
+VALU_PEAK_G_WAVE_INSTR = 545.0
 
 
 def usable_cores() -> int:
@@ -163,7 +168,13 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kernel_ms_max, "algorithmic_bytes_per_perm": ALGO_BYTES_PER_PERM,
-                     "note": "integer-ALU bound: ~1e5 VALU instructions per 320 B; see DESIGN.md"},
+                     "note": "HBM traffic equals the algorithmic bytes; the kernel is VALU-issue bound "
+                             "(~95 k instructions per 320 B), see valu_issue and DESIGN.md"},
+        "valu_issue": {"bound": "v_mad_u64_u32 issue", "mads_per_perm": MADS_PER_PERM,
+                       "achieved": MADS_PER_PERM * n / (kernel_ms_max * 1e-3) / 64 / 1e9,
+                       "peak": VALU_PEAK_G_WAVE_INSTR, "unit": "G wave-instr/s",
+                       "frac": MADS_PER_PERM * n / (kernel_ms_max * 1e-3) / 64 / 1e9 / VALU_PEAK_G_WAVE_INSTR,
+                       "note": "64-bit multiply-adds only (87% of the 64-bit-class VALU work); the binding bound"},
         "digest": ["%016x" % d for d in digest],
     }
     if world == 1 and not args.no_cpu_baseline:
