@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -346,7 +347,65 @@ int hades252_perm_batch_dev(void *d_states, size_t n_perms, void *stream) {
     return hades252_perm_batch_dev_ex(d_states, n_perms, stream, HADES252_KERNEL_DEFAULT);
 }
 
+// ---- host-pointer path ------------------------------------------------------------------------
+// A small pool of (stream, device buffer) slots so that a call does not pay hipMalloc / hipFree /
+// hipStreamCreate (about 1 ms together) every time -- the reference's callers issue many small
+// calls.  Slots are created on demand, handed out exclusively and returned; the pool is bounded by
+// the peak number of concurrent calls (x2 for chunked batches) and by 40 MiB per slot.
+struct HostSlot {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    void *buf = nullptr;
+    size_t cap = 0;
+};
+static std::mutex g_pool_mu;
+static std::vector<HostSlot> g_pool;
+
+static int acquire_slot(size_t bytes, HostSlot &out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HostSlot s;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        int best = -1;
+        for (int i = 0; i < (int)g_pool.size(); i++) {
+            if (g_pool[i].device != dev) continue;
+            if (best < 0 || (g_pool[best].cap < bytes && g_pool[i].cap > g_pool[best].cap)) best = i;
+            if (g_pool[best].cap >= bytes) break;
+        }
+        if (best >= 0) {
+            s = g_pool[best];
+            g_pool.erase(g_pool.begin() + best);
+        }
+    }
+    if (s.device < 0) {
+        s.device = dev;
+        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    }
+    if (s.cap < bytes) {
+        if (s.buf) (void)hipFree(s.buf);
+        s.buf = nullptr;
+        s.cap = 0;
+        hipError_t e = hipMalloc(&s.buf, bytes);
+        if (e != hipSuccess) {
+            tl_last_hip_error = (int)e;
+            (void)hipGetLastError();
+            (void)hipStreamDestroy(s.stream);
+            return HADES252_ERR_HIP;
+        }
+        s.cap = bytes;
+    }
+    out = s;
+    return HADES252_OK;
+}
+
+static void release_slot(const HostSlot &s) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.push_back(s);
+}
+
 // Host batch on the current device: chunked, double-buffered H2D / kernel / D2H on two streams.
+// `bytes_format` inputs have already been validated (all < p).
 static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, bool bytes_format) {
     if (n_perms == 0) return HADES252_OK;
     if (states == nullptr) return HADES252_ERR_INVALID_ARG;
@@ -354,42 +413,28 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
     if (rc != HADES252_OK) return rc;
     const size_t kChunk = (size_t)1 << 18;                // 40 MiB of states per chunk
     const size_t chunk = n_perms < kChunk ? n_perms : kChunk;
-    void *dbuf[2] = {nullptr, nullptr};
-    hipStream_t st[2] = {nullptr, nullptr};
-    int *d_bad = nullptr;
-    int result = HADES252_OK;
-    auto cleanup = [&]() {
-        for (int i = 0; i < 2; i++) {
-            if (st[i]) (void)hipStreamDestroy(st[i]);
-            if (dbuf[i]) (void)hipFree(dbuf[i]);
-        }
-        if (d_bad) (void)hipFree(d_bad);
-    };
-#define TRY_CLEAN(expr)                              \
-    do {                                             \
-        hipError_t e_ = (expr);                      \
-        if (e_ != hipSuccess) {                      \
-            tl_last_hip_error = (int)e_;             \
-            (void)hipGetLastError();                 \
-            cleanup();                               \
-            return HADES252_ERR_HIP;                 \
-        }                                            \
-    } while (0)
     const int nbuf = n_perms > chunk ? 2 : 1;
-    for (int i = 0; i < nbuf; i++) {
-        TRY_CLEAN(hipMalloc(&dbuf[i], chunk * 160));
-        TRY_CLEAN(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
-    }
-    if (bytes_format) {
-        TRY_CLEAN(hipMalloc((void **)&d_bad, sizeof(int)));
-        TRY_CLEAN(hipMemset(d_bad, 0, sizeof(int)));
-    }
     uint8_t *h = (uint8_t *)states;
+    HostSlot slot[2];
+    int have = 0;
+    bool registered = false;
+    auto finish = [&](int code) {
+        for (int i = 0; i < have; i++) {
+            (void)hipStreamSynchronize(slot[i].stream);
+            release_slot(slot[i]);
+        }
+        if (registered) (void)hipHostUnregister(h);
+        return code;
+    };
+    for (int i = 0; i < nbuf; i++) {
+        rc = acquire_slot(chunk * 160, slot[i]);
+        if (rc != HADES252_OK) return finish(rc);
+        have++;
+    }
     // Large batches: page-lock the caller's buffer in place for the duration of the call, so the
     // chunk copies are true DMA and overlap with the kernels (pageable copies are staged by the
     // runtime at ~15 GB/s).  If registration is refused (e.g. the range is already registered by
     // the caller) the pageable path is used; HADES252_HOST_PIN=0 disables the attempt.
-    bool registered = false;
     static const bool pin_enabled = []() {
         const char *e = getenv("HADES252_HOST_PIN");
         return !(e && e[0] == '0');
@@ -400,57 +445,34 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
         else
             (void)hipGetLastError();
     }
-    auto cleanup0 = cleanup;
-    auto cleanup_all = [&]() {
-        if (registered) {
-            (void)hipHostUnregister(h);
-            registered = false;
-        }
-        cleanup0();
-    };
-#undef TRY_CLEAN
-#define TRY_CLEAN(expr)                              \
+#define TRY_FIN(expr)                                \
     do {                                             \
         hipError_t e_ = (expr);                      \
         if (e_ != hipSuccess) {                      \
             tl_last_hip_error = (int)e_;             \
             (void)hipGetLastError();                 \
-            cleanup_all();                           \
-            return HADES252_ERR_HIP;                 \
+            return finish(HADES252_ERR_HIP);         \
         }                                            \
     } while (0)
     int k = 0;
     for (size_t off = 0; off < n_perms; off += chunk, k ^= (nbuf - 1)) {
         size_t n = n_perms - off < chunk ? n_perms - off : chunk;
-        TRY_CLEAN(hipMemcpyAsync(dbuf[k], h + off * 160, n * 160, hipMemcpyHostToDevice, st[k]));
+        void *d = slot[k].buf;
+        hipStream_t st = slot[k].stream;
+        TRY_FIN(hipMemcpyAsync(d, h + off * 160, n * 160, hipMemcpyHostToDevice, st));
         if (bytes_format) {
-            rc = hades252_from_bytes_dev(dbuf[k], dbuf[k], n * 5, d_bad, st[k]);
-            if (rc == HADES252_OK) rc = hades252_perm_batch_dev(dbuf[k], n, st[k]);
-            if (rc == HADES252_OK) rc = hades252_to_bytes_dev(dbuf[k], dbuf[k], n * 5, st[k]);
+            rc = hades252_from_bytes_dev(d, d, n * 5, nullptr, st);
+            if (rc == HADES252_OK) rc = hades252_perm_batch_dev(d, n, st);
+            if (rc == HADES252_OK) rc = hades252_to_bytes_dev(d, d, n * 5, st);
         } else {
-            rc = hades252_perm_batch_dev(dbuf[k], n, st[k]);
+            rc = hades252_perm_batch_dev(d, n, st);
         }
-        if (rc != HADES252_OK) {
-            for (int i = 0; i < nbuf; i++) (void)hipStreamSynchronize(st[i]);
-            cleanup_all();
-            return rc;
-        }
-        if (bytes_format) {
-            // results of a batch with a non-canonical input are not written back
-            int bad = 0;
-            TRY_CLEAN(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st[k]));
-            TRY_CLEAN(hipStreamSynchronize(st[k]));
-            if (bad != 0) {
-                result = HADES252_ERR_NOT_CANONICAL;
-                break;
-            }
-        }
-        TRY_CLEAN(hipMemcpyAsync(h + off * 160, dbuf[k], n * 160, hipMemcpyDeviceToHost, st[k]));
+        if (rc != HADES252_OK) return finish(rc);
+        TRY_FIN(hipMemcpyAsync(h + off * 160, d, n * 160, hipMemcpyDeviceToHost, st));
     }
-    for (int i = 0; i < nbuf; i++) TRY_CLEAN(hipStreamSynchronize(st[i]));
-#undef TRY_CLEAN
-    cleanup_all();
-    return result;
+    for (int i = 0; i < have; i++) TRY_FIN(hipStreamSynchronize(slot[i].stream));
+#undef TRY_FIN
+    return finish(HADES252_OK);
 }
 
 int hades252_perm_batch(uint64_t *states, size_t n_perms) {

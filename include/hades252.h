@@ -23,8 +23,10 @@
  *     pointer after returning.  `_dev` functions take device pointers valid on the CURRENT HIP
  *     device, enqueue on `stream` (a hipStream_t, NULL = default stream) and return without
  *     synchronising; buffers must stay alive until the stream has drained.
- *   - Re-entrant: no mutable global state; any number of host threads may call concurrently
- *     (the reference's strategy is a stateless ZST, src/strategies/scalar.rs:11-20).
+ *   - Thread-safe and re-entrant: any number of host threads may call concurrently (the reference's
+ *     strategy is a stateless ZST, src/strategies/scalar.rs:11-20).  The only internal state is a
+ *     mutex-protected pool of scratch slots (stream + device buffer) used by the host-pointer
+ *     entry points; device tables are immutable.
  *   - There is no CPU fallback: without a usable HIP device the calls fail with
  *     HADES252_ERR_NO_DEVICE / HADES252_ERR_HIP.
  */

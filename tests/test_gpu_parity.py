@@ -380,3 +380,28 @@ def test_perm_trace(torch_cuda, H, oracle):
     out = dev.clone()
     H.ScalarStrategy().perm(out)
     assert torch.equal(tr[66].reshape(-1), out.reshape(-1))
+
+
+def test_host_path_concurrent_threads(torch_cuda, hades_lib, oracle):
+    """The library is re-entrant (the reference strategy is a stateless ZST): many host threads
+    permuting their own buffers at once, small and chunked sizes mixed."""
+    import threading
+    sizes = [1, 7, 300, 5000, (1 << 18) + 77, 64, 1000, 3]
+    bufs = [oracle.gen_b(1000 * i, 5 * n) for i, n in enumerate(sizes)]
+    exp = [oracle.perm_batch(b) for b in bufs]
+    rcs = [None] * len(sizes)
+
+    def work(i):
+        for _ in range(2 if sizes[i] > 10000 else 6):
+            x = bufs[i].copy()
+            rcs[i] = hades_lib.hades252_perm_batch(x.ctypes.data_as(ctypes.c_void_p), sizes[i])
+            if rcs[i] != 0 or not (x == exp[i]).all():
+                rcs[i] = -99
+                return
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(sizes))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert rcs == [0] * len(sizes)

@@ -52,3 +52,10 @@ for logn in (20, 22, 24):
     s = H.ScalarStrategy()
     dt = timed(lambda: s.perm(host), reps=2)
     print("n=2^%-2d host path %9.3f ms  %8.2f Mperm/s (%.2f GB/s each way)" % (logn, dt * 1e3, n / dt / 1e6, 160 * n / dt / 1e9))
+
+print("== small-call latency, host-pointer path (pooled stream + buffer)")
+for n in (1, 64, 4096):
+    host = H.gen_b(5 * n, dev).cpu().numpy().view(np.uint64).reshape(-1).copy()
+    s = H.ScalarStrategy()
+    dt = timed(lambda: s.perm(host), reps=50)
+    print("n=%-5d host call %8.1f us" % (n, dt * 1e6))
