@@ -81,7 +81,7 @@ def cpu_baseline_and_check(H, torch, device, n_sample: int):
     return {
         "value": n_sample / tall, "unit": "permutations/s", "cores": cores, "kind": "port",
         "sample": "first %d permutations of the same generator-B workload, %d threads "
-                  "(C restatement of the reference CPU path, gcc -O3 -march=native)" % (n_sample, cores),
+                  "(C restatement of the reference CPU path, gcc -O3 -march=x86-64-v3)" % (n_sample, cores),
         "single_thread_value": n1 / t1,
     }, ok
 

@@ -405,3 +405,21 @@ def test_host_path_concurrent_threads(torch_cuda, hades_lib, oracle):
     for t in th:
         t.join()
     assert rcs == [0] * len(sizes)
+
+
+def test_merkle_sharded_emulated(torch_cuda, H, oracle):
+    """Multi-GPU Merkle decomposition emulated on one device: every 'rank' builds
+    its sub-tree roots, the gathered sub-roots are finished, result == single-device root."""
+    torch = torch_cuda
+    from hades252_amd import merkle
+    tag = S.to_mont(15)
+    n = 1 << 16
+    leaves = H.gen_b(n, "cuda")
+    ref = H.merkle4_root(leaves, tag, 1)
+    for world in (1, 2, 4, 8):
+        per_rank = n // world
+        parts = [merkle.local_subroots(leaves[r * per_rank:(r + 1) * per_rank], n, world, tag, 1)
+                 for r in range(world)]
+        root = merkle.finish_from_subroots(torch.cat(parts), tag, 1)
+        assert torch.equal(root.view(-1), ref.view(-1))
+    assert torch.equal(merkle.merkle4_root_sharded(leaves, n, tag, 1).view(-1), ref.view(-1))

@@ -55,3 +55,16 @@ def test_host_buffer_validation():
         s.perm(np.zeros(20, dtype=np.int32))
     with pytest.raises(ValueError):
         s.perm(np.zeros(19, dtype=np.uint64))      # not a whole state: reference panics (scalar.rs:48)
+
+
+def test_merkle_subtree_split():
+    from hades252_amd import merkle
+    # 2^24 leaves over 8 GPUs = two complete 10-level sub-trees (2^20 leaves) per GPU
+    assert merkle.subtree_split(1 << 24, 8) == (1 << 20, 2)
+    assert merkle.subtree_split(1 << 24, 1) == (1 << 24, 1)
+    assert merkle.subtree_split(1 << 24, 4) == (1 << 22, 1)
+    assert merkle.subtree_split(1 << 24, 2) == (1 << 22, 2)
+    assert merkle.subtree_split(16, 4) == (4, 1)
+    for bad in ((1 << 23, 2), (1 << 24, 3), (4, 4)):
+        with pytest.raises(ValueError):
+            merkle.subtree_split(*bad)
