@@ -39,6 +39,14 @@ HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak, MI355X_MICROARCH.md
 # v_mad_u64_u32 issue rate measured by tools/ubench2.hip (profiles/ubench2_*.txt).
 MADS_PER_PERM = 99 * 387 + 64 * 153 + 67 * 265
 VALU_PEAK_G_WAVE_INSTR = 545.0
+# Issue-cycle model: 64-bit-class VALU ops (multiply-adds, 64-bit shifts) occupy a SIMD for 4 cycles
+# per wave-instruction, 32-bit ops for 2 (MI355X_MICROARCH.md: SIMD-32 issues wave64 in 2 cycles; the
+# 64-bit integer ops run at half that rate, tools/ubench*.hip).  Counts per permutation from the ISA
+# of k_perm_fast / rocprofv3 SQ_INSTS_VALU = 88.7 k.
+OPS64_PER_PERM = MADS_PER_PERM + 9400
+OPS32_PER_PERM = 88700 - OPS64_PER_PERM
+PEAK_CLOCK_HZ = 2.4e9
+N_SIMD = 1024
 
 
 def usable_cores() -> int:
@@ -174,7 +182,11 @@ def main():
                        "achieved": MADS_PER_PERM * n / (kernel_ms_max * 1e-3) / 64 / 1e9,
                        "peak": VALU_PEAK_G_WAVE_INSTR, "unit": "G wave-instr/s",
                        "frac": MADS_PER_PERM * n / (kernel_ms_max * 1e-3) / 64 / 1e9 / VALU_PEAK_G_WAVE_INSTR,
-                       "note": "64-bit multiply-adds only (87% of the 64-bit-class VALU work); the binding bound"},
+                       "issue_cycle_frac": (OPS64_PER_PERM * 4 + OPS32_PER_PERM * 2) * (n / 64.0) / N_SIMD
+                                           / (kernel_ms_max * 1e-3 * PEAK_CLOCK_HZ),
+                       "note": "64-bit multiply-adds only (87% of the 64-bit-class VALU work); the binding bound. "
+                               "issue_cycle_frac = modelled VALU issue cycles (4 per 64-bit op, 2 per 32-bit op) / "
+                               "(kernel time x 2.4 GHz peak clock)"},
         "digest": ["%016x" % d for d in digest],
     }
     if world == 1 and not args.no_cpu_baseline:

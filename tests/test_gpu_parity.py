@@ -423,3 +423,35 @@ def test_merkle_sharded_emulated(torch_cuda, H, oracle):
         root = merkle.finish_from_subroots(torch.cat(parts), tag, 1)
         assert torch.equal(root.view(-1), ref.view(-1))
     assert torch.equal(merkle.merkle4_root_sharded(leaves, n, tag, 1).view(-1), ref.view(-1))
+
+
+def test_per_op_kernels_edge_values(torch_cuda, H, oracle):
+    """Field-operation edge cases through the per-op kernels: operands 0, 1, p-1, p-2, R, values
+    that make word + constant cross p, etc. (saturated 8x32 arithmetic of csrc/fr32.cuh)."""
+    torch = torch_cuda
+    rng = random.Random(77)
+    edge = [0, 1, 2, P - 1, P - 2, R, P - R, (1 << 255) % P, P - (1 << 32), 0xFFFFFFFF, 0xFFFFFFFF00000000,
+            (P - 1) // 2, (P + 1) // 2, (1 << 224) - 1]
+    ark = S.round_constants()
+    # complements of the first round constants (Montgomery domain): w + c == 0, p - 1, 1 (mod p)
+    for c in ark[:10]:
+        cm = S.to_mont(c)
+        edge += [(P - cm) % P, (P - cm - 1) % P, (P - cm + 1) % P]
+    n = 1024
+    vals = [rng.choice(edge) if rng.random() < 0.8 else rng.randrange(P) for _ in range(5 * n)]
+    inp = np.array([l for v in vals for l in limbs_of(v)], dtype=np.uint64)
+    strat = H.ScalarStrategy()
+    for rnd in (0, 1, 33, 66):
+        buf = to_dev(torch, inp)
+        strat.add_round_key(H.RoundConstantsIter(5 * rnd), buf)
+        assert (to_host(buf) == oracle.add_round_key(inp, rnd)).all()
+    buf = to_dev(torch, inp)
+    strat.quintic_s_box(buf)
+    assert (to_host(buf) == oracle.quintic_s_box(inp)).all()
+    buf = to_dev(torch, inp)
+    strat.mul_matrix(H.RoundConstantsIter(), buf)
+    assert (to_host(buf) == oracle.mul_matrix(inp)).all()
+    # wire format on the same edge values
+    canon = np.frombuffer(b"".join(S.from_mont(v).to_bytes(32, "little") for v in vals), dtype=np.uint64).copy()
+    assert (to_host(H.to_bytes(to_dev(torch, inp))) == canon).all()
+    assert (to_host(H.from_bytes(to_dev(torch, canon))) == inp).all()
