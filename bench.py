@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 default (fast), 1 literal, 2 fast")
     ap.add_argument("--cpu-sample", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # test hooks for boxes with fewer GPUs than ranks (control-flow check of the N>1 path only)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (testing)")
     args = ap.parse_args()
 
     import torch
@@ -117,10 +120,11 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: hades252_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.single_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        sharding.init_process_group("nccl")
+        sharding.init_process_group(args.dist_backend)
 
     n = args.perms_per_gpu
     first_perm, _ = sharding.weak_shard(rank, n)

@@ -42,10 +42,18 @@ def init_process_group(backend: str):
     return dist
 
 
+def _comm_device(device):
+    """Tensors handed to collectives live on the GPU for nccl (RCCL) and on the host for gloo."""
+    import torch.distributed as dist
+    if dist.get_backend() == "gloo":
+        return "cpu"
+    return device
+
+
 def barrier(device=None) -> None:
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        if device is not None and getattr(device, "type", "cpu") == "cuda":
+        if dist.get_backend() != "gloo" and device is not None and getattr(device, "type", "cpu") == "cuda":
             dist.barrier(device_ids=[device.index])
         else:
             dist.barrier()
@@ -57,7 +65,7 @@ def reduce_max(value: float, device="cpu") -> float:
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -67,7 +75,7 @@ def reduce_sum_int(value: int, device="cpu") -> int:
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return value
-    t = torch.tensor([value], dtype=torch.int64, device=device)
+    t = torch.tensor([value], dtype=torch.int64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
 
@@ -83,7 +91,7 @@ def combine_digests(digest4: List[int], device="cpu") -> List[int]:
     halves = []
     for d in digest4:
         halves += [d & 0xFFFFFFFF, (d >> 32) & 0xFFFFFFFF]
-    t = torch.tensor(halves, dtype=torch.int64, device=device)
+    t = torch.tensor(halves, dtype=torch.int64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     h = [int(x) for x in t.cpu().tolist()]
     return [(h[2 * k] + (h[2 * k + 1] << 32)) & M64 for k in range(4)]

@@ -1,0 +1,43 @@
+"""bench.py contract: one JSON line with the required keys; the N>1 control flow (barrier, max over
+ranks, digest combination, global shard indices) run as two ranks -- sharing cuda:0 over gloo, because
+the test box has one GPU -- produces the same output digest as the single-rank job."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def run(cmd):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "bench.py must print exactly one JSON line"
+    return json.loads(lines[0])
+
+
+def test_bench_single_and_two_ranks_agree():
+    per = 1 << 18
+    one = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--perms-per-gpu", str(2 * per),
+               "--cpu-sample", "4096"])
+    for k in REQUIRED + ["cpu_baseline"]:
+        assert k in one, k
+    assert one["n_gpus"] == 1 and one["parity_vs_cpu_sample"] is True
+    assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1
+    assert one["cpu_baseline"]["kind"] == "port" and one["cpu_baseline"]["cores"] >= 1
+    assert one["vs_baseline"] is None and one["scaling"] == "weak" and one["config"]["workload"]
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200),
+               "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--perms-per-gpu", str(per),
+               "--dist-backend", "gloo", "--single-device"])
+    assert two["n_gpus"] == 2 and "cpu_baseline" not in two
+    # same global batch (2 x per states, same generator indices), same number of passes
+    assert two["digest"] == one["digest"]
