@@ -35,10 +35,7 @@ def _stale() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
-    flags = list(FLAGS)
-    if os.path.exists(os.path.join(CSRC, "hades_fast.cuh")):
-        flags.append("-DHADES_HAVE_FAST")
-    cmd = [HIPCC] + flags + ["-o", LIB] + SOURCES
+    cmd = [HIPCC] + FLAGS + ["-o", LIB] + SOURCES
     if verbose:
         print("[hades252_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, cwd=CSRC, check=True)

@@ -14,9 +14,7 @@
 #include "hades_constants.inc"
 #include "hades_literal.cuh"
 #include "staging.cuh"
-#ifdef HADES_HAVE_FAST
 #include "hades_fast.cuh"
-#endif
 
 using namespace hades;
 
@@ -29,9 +27,7 @@ __device__ const uint32_t d_mds_mont[25][8] = HADES_MDS_MONT_INIT;
 __device__ const uint32_t d_r2[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu,
                                      0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
 
-#ifdef HADES_HAVE_FAST
 __device__ const FastTables d_fast = {HADES_FAST_ROUND_INIT, HADES_FAST_FINAL_F};
-#endif
 
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
@@ -128,27 +124,6 @@ __global__ void __launch_bounds__(kBlock) k_to_bytes(const uint8_t *__restrict__
     wave_store_records<1>(out, rec0, n, slab, st);
 }
 
-// Merkle level: lane i hashes children[4i..4i+4) -> parents[i]
-__global__ void __launch_bounds__(kBlock) k_merkle4_level_literal(const uint8_t *__restrict__ children,
-                                                                  uint8_t *__restrict__ parents, size_t n_parents,
-                                                                  Fr tag, int out_idx) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t *slab = wave_slab<4>(lds);
-    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
-    Fr ch[4];
-    wave_load_records<4>(children, rec0, n_parents, slab, ch);
-    Fr st[5] = {tag, ch[0], ch[1], ch[2], ch[3]};
-    LiteralView V{d_ark_mont, d_mds_mont};
-    lit_perm(V, st);
-    Fr out[1];
-    out[0] = st[0];
-#pragma unroll
-    for (int w = 1; w < 5; w++)
-        if (out_idx == w) out[0] = st[w];
-    wave_store_records<1>(parents, rec0, n_parents, slab, out);
-}
-
-#ifdef HADES_HAVE_FAST
 // The shipped hot path: one permutation per lane, scale-tracked formulation (hades_fast.cuh).
 // __launch_bounds__(256, 4): 4 waves per SIMD = at most 128 VGPRs; the kernel needs 108 and does
 // not spill.  (2 waves/SIMD: same speed; 5: spills, 6 % slower; 6: 35 % slower -- measured.)
@@ -179,7 +154,6 @@ __global__ void __launch_bounds__(kBlock, 4) k_merkle4_level_fast(const uint8_t 
     fast_perm<1>(&d_fast, st, out, out_idx);
     wave_store_records<1>(parents, rec0, n_parents, slab, out);
 }
-#endif
 
 __device__ __forceinline__ uint64_t splitmix_limb(uint64_t seed, uint64_t idx) {
     uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
@@ -257,11 +231,12 @@ static thread_local int tl_last_hip_error = 0;
         }                                            \
     } while (0)
 
+// device buffers are moved with 16-byte vector loads/stores
+static inline bool misaligned(const void *p) { return ((uintptr_t)p & 15u) != 0; }
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 static inline size_t lds_for(int nw) { return (size_t)kWavesPerBlock * lds_wave_bytes(nw); }
 static constexpr size_t kMaxLaunchRecords = (size_t)1 << 30;   // grid.x * 256 per launch
 
-#ifdef HADES_HAVE_FAST
 static int launch_perm_fast(uint8_t *states, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_perm_fast, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, states, n);
     return HADES252_OK;
@@ -272,7 +247,6 @@ static int launch_merkle4_level_fast(const uint8_t *children, uint8_t *parents, 
                        tag, out_idx);
     return HADES252_OK;
 }
-#endif
 
 static int check_device() {
     int n = 0;
@@ -317,24 +291,18 @@ const char *hades252_version(void) { return "hades252-amd 0.1.0 (gfx950)"; }
 // ---- perm ---------------------------------------------------------------------------------
 int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int kernel) {
     if (n_perms == 0) return HADES252_OK;
-    if (d_states == nullptr) return HADES252_ERR_INVALID_ARG;
+    if (d_states == nullptr || misaligned(d_states)) return HADES252_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     uint8_t *p = (uint8_t *)d_states;
-#ifdef HADES_HAVE_FAST
     if (kernel == HADES252_KERNEL_DEFAULT) kernel = HADES252_KERNEL_FAST;
-#else
-    if (kernel == HADES252_KERNEL_DEFAULT) kernel = HADES252_KERNEL_LITERAL;
-#endif
     for (size_t off = 0; off < n_perms; off += kMaxLaunchRecords) {
         size_t n = n_perms - off < kMaxLaunchRecords ? n_perms - off : kMaxLaunchRecords;
         if (kernel == HADES252_KERNEL_LITERAL) {
             hipLaunchKernelGGL(k_states_literal<OP_PERM>, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s,
                                p + off * 160, n, 0);
-#ifdef HADES_HAVE_FAST
         } else if (kernel == HADES252_KERNEL_FAST) {
             int rc = launch_perm_fast(p + off * 160, n, s);
             if (rc != HADES252_OK) return rc;
-#endif
         } else {
             return HADES252_ERR_INVALID_ARG;
         }
@@ -541,7 +509,9 @@ int hades252_perm_batch_multi(uint64_t *states, size_t n_perms, int n_devices) {
 
 int hades252_perm_trace_dev(const void *d_states, void *d_trace, size_t n_perms, void *stream) {
     if (n_perms == 0) return HADES252_OK;
-    if (d_states == nullptr || d_trace == nullptr || n_perms > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    if (d_states == nullptr || d_trace == nullptr || n_perms > kMaxLaunchRecords || misaligned(d_states) ||
+        misaligned(d_trace))
+        return HADES252_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_perm_trace_literal, dim3(blocks_for(n_perms)), dim3(kBlock), lds_for(5), (hipStream_t)stream,
                        (const uint8_t *)d_states, (uint8_t *)d_trace, n_perms);
     HIP_TRY(hipGetLastError());
@@ -552,7 +522,8 @@ int hades252_perm_trace_dev(const void *d_states, void *d_trace, size_t n_perms,
 #define STATES_OP(NAME, OPV, NEEDS_ROUND)                                                              \
     int NAME(void *d_states, size_t n_states, int round, void *stream) {                               \
         if (n_states == 0) return HADES252_OK;                                                         \
-        if (d_states == nullptr || n_states > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;      \
+        if (d_states == nullptr || n_states > kMaxLaunchRecords || misaligned(d_states))               \
+            return HADES252_ERR_INVALID_ARG;                                                           \
         if (NEEDS_ROUND && (round < 0 || round >= hades252_rounds())) return HADES252_ERR_INVALID_ARG; \
         hipLaunchKernelGGL(k_states_literal<OPV>, dim3(blocks_for(n_states)), dim3(kBlock), lds_for(5), \
                            (hipStream_t)stream, (uint8_t *)d_states, n_states, round);                 \
@@ -566,7 +537,7 @@ STATES_OP(hades252_apply_partial_round_dev, OP_PARTIAL, true)
 
 int hades252_mul_matrix_dev(void *d_states, size_t n_states, void *stream) {
     if (n_states == 0) return HADES252_OK;
-    if (d_states == nullptr || n_states > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    if (d_states == nullptr || n_states > kMaxLaunchRecords || misaligned(d_states)) return HADES252_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_states_literal<OP_MDS>, dim3(blocks_for(n_states)), dim3(kBlock), lds_for(5),
                        (hipStream_t)stream, (uint8_t *)d_states, n_states, 0);
     HIP_TRY(hipGetLastError());
@@ -575,7 +546,7 @@ int hades252_mul_matrix_dev(void *d_states, size_t n_states, void *stream) {
 
 int hades252_quintic_s_box_dev(void *d_scalars, size_t n_scalars, void *stream) {
     if (n_scalars == 0) return HADES252_OK;
-    if (d_scalars == nullptr || n_scalars > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    if (d_scalars == nullptr || n_scalars > kMaxLaunchRecords || misaligned(d_scalars)) return HADES252_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_sbox, dim3(blocks_for(n_scalars)), dim3(kBlock), lds_for(1), (hipStream_t)stream,
                        (uint8_t *)d_scalars, n_scalars);
     HIP_TRY(hipGetLastError());
@@ -585,7 +556,9 @@ int hades252_quintic_s_box_dev(void *d_scalars, size_t n_scalars, void *stream) 
 // ---- wire format ----------------------------------------------------------------------------
 int hades252_from_bytes_dev(const void *d_bytes, void *d_limbs, size_t n_scalars, int *d_bad_count, void *stream) {
     if (n_scalars == 0) return HADES252_OK;
-    if (d_bytes == nullptr || d_limbs == nullptr || n_scalars > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    if (d_bytes == nullptr || d_limbs == nullptr || n_scalars > kMaxLaunchRecords || misaligned(d_bytes) ||
+        misaligned(d_limbs))
+        return HADES252_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_from_bytes, dim3(blocks_for(n_scalars)), dim3(kBlock), lds_for(1), (hipStream_t)stream,
                        (const uint8_t *)d_bytes, (uint8_t *)d_limbs, n_scalars, d_bad_count);
     HIP_TRY(hipGetLastError());
@@ -594,7 +567,9 @@ int hades252_from_bytes_dev(const void *d_bytes, void *d_limbs, size_t n_scalars
 
 int hades252_to_bytes_dev(const void *d_limbs, void *d_bytes, size_t n_scalars, void *stream) {
     if (n_scalars == 0) return HADES252_OK;
-    if (d_bytes == nullptr || d_limbs == nullptr || n_scalars > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    if (d_bytes == nullptr || d_limbs == nullptr || n_scalars > kMaxLaunchRecords || misaligned(d_bytes) ||
+        misaligned(d_limbs))
+        return HADES252_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_to_bytes, dim3(blocks_for(n_scalars)), dim3(kBlock), lds_for(1), (hipStream_t)stream,
                        (const uint8_t *)d_limbs, (uint8_t *)d_bytes, n_scalars);
     HIP_TRY(hipGetLastError());
@@ -606,21 +581,16 @@ int hades252_merkle4_level_dev(const void *d_children, void *d_parents, size_t n
                                int out_idx, void *stream) {
     if (n_parents == 0) return HADES252_OK;
     if (d_children == nullptr || d_parents == nullptr || tag_mont == nullptr || out_idx < 0 || out_idx >= 5 ||
-        n_parents > kMaxLaunchRecords)
+        n_parents > kMaxLaunchRecords || misaligned(d_children) || misaligned(d_parents))
         return HADES252_ERR_INVALID_ARG;
     Fr tag;
     for (int k = 0; k < 4; k++) {
         tag.l[2 * k] = (uint32_t)tag_mont[k];
         tag.l[2 * k + 1] = (uint32_t)(tag_mont[k] >> 32);
     }
-#ifdef HADES_HAVE_FAST
     int rc = launch_merkle4_level_fast((const uint8_t *)d_children, (uint8_t *)d_parents, n_parents, tag, out_idx,
                                        (hipStream_t)stream);
     if (rc != HADES252_OK) return rc;
-#else
-    hipLaunchKernelGGL(k_merkle4_level_literal, dim3(blocks_for(n_parents)), dim3(kBlock), lds_for(4),
-                       (hipStream_t)stream, (const uint8_t *)d_children, (uint8_t *)d_parents, n_parents, tag, out_idx);
-#endif
     HIP_TRY(hipGetLastError());
     return HADES252_OK;
 }
@@ -672,7 +642,7 @@ int hades252_gen_b_dev(void *d_scalars, uint64_t first_elem, size_t n_elems, uin
 
 int hades252_gen_a_dev(void *d_scalars, uint64_t first_elem, size_t n_elems, void *stream) {
     if (n_elems == 0) return HADES252_OK;
-    if (d_scalars == nullptr || n_elems > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    if (d_scalars == nullptr || n_elems > kMaxLaunchRecords || misaligned(d_scalars)) return HADES252_ERR_INVALID_ARG;
     hipLaunchKernelGGL(k_gen_a, dim3(blocks_for(n_elems)), dim3(kBlock), lds_for(1), (hipStream_t)stream,
                        (uint8_t *)d_scalars, first_elem, n_elems);
     HIP_TRY(hipGetLastError());

@@ -22,7 +22,9 @@
  *   - The caller owns every buffer.  Host-pointer functions are synchronous and keep no
  *     pointer after returning.  `_dev` functions take device pointers valid on the CURRENT HIP
  *     device, enqueue on `stream` (a hipStream_t, NULL = default stream) and return without
- *     synchronising; buffers must stay alive until the stream has drained.
+ *     synchronising; buffers must stay alive until the stream has drained.  Device pointers must
+ *     be 16-byte aligned (hipMalloc'ed buffers and whole-state offsets into them are); host
+ *     pointers need only their natural 8-byte alignment.
  *   - Thread-safe and re-entrant: any number of host threads may call concurrently (the reference's
  *     strategy is a stateless ZST, src/strategies/scalar.rs:11-20).  The only internal state is a
  *     mutex-protected pool of scratch slots (stream + device buffer) used by the host-pointer

@@ -455,3 +455,9 @@ def test_per_op_kernels_edge_values(torch_cuda, H, oracle):
     canon = np.frombuffer(b"".join(S.from_mont(v).to_bytes(32, "little") for v in vals), dtype=np.uint64).copy()
     assert (to_host(H.to_bytes(to_dev(torch, inp))) == canon).all()
     assert (to_host(H.from_bytes(to_dev(torch, canon))) == inp).all()
+
+
+def test_misaligned_device_pointer_rejected(torch_cuda, hades_lib):
+    t = torch_cuda.zeros(64, dtype=torch_cuda.int64, device="cuda")
+    assert hades_lib.hades252_perm_batch_dev(t.data_ptr() + 8, 1, None) == -1
+    assert hades_lib.hades252_perm_batch_dev(t.data_ptr() + 32, 1, None) == 0
