@@ -461,3 +461,18 @@ def test_misaligned_device_pointer_rejected(torch_cuda, hades_lib):
     t = torch_cuda.zeros(64, dtype=torch_cuda.int64, device="cuda")
     assert hades_lib.hades252_perm_batch_dev(t.data_ptr() + 8, 1, None) == -1
     assert hades_lib.hades252_perm_batch_dev(t.data_ptr() + 32, 1, None) == 0
+
+
+def test_exhaustive_edge_tuples(torch_cuda, H, oracle):
+    """Every 5-tuple over 14 edge values (0, 1, p-1, R, 2^255 mod p, all-ones limbs, ...) = 537 824
+    states, shipped kernel vs the CPU oracle, all bits."""
+    import itertools
+    torch = torch_cuda
+    edge = [0, 1, 2, P - 1, P - 2, R, P - R, (1 << 255) % P, (1 << 254) - 1, 0xFFFFFFFF, P - (1 << 32),
+            0xFFFFFFFF00000000, (P - 1) // 2, (1 << 128) - 1]
+    tab = np.array([limbs_of(v) for v in edge], dtype=np.uint64)
+    idx = np.array(list(itertools.product(range(len(edge)), repeat=5)), dtype=np.int64)
+    inp = np.ascontiguousarray(tab[idx]).reshape(-1)
+    buf = to_dev(torch, inp)
+    H.ScalarStrategy(2).perm(buf)
+    assert (to_host(buf) == oracle.perm_batch(inp)).all()
