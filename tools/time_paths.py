@@ -59,3 +59,17 @@ for n in (1, 64, 4096):
     s = H.ScalarStrategy()
     dt = timed(lambda: s.perm(host), reps=50)
     print("n=%-5d host call %8.1f us" % (n, dt * 1e6))
+
+print("== wire format on device (BlsScalar::from_bytes / to_bytes), per-round trace")
+n = 1 << 24
+limbs = H.gen_b(n, dev)
+canon = H.to_bytes(limbs)
+out = torch.empty_like(limbs)
+dt = timed(lambda: H.to_bytes(limbs, out), reps=5)
+print("to_bytes   n=2^24 scalars %8.3f ms  %8.2f G scalars/s  %7.1f GB/s (64 B/scalar)" % (dt * 1e3, n / dt / 1e9, 64 * n / dt / 1e9))
+dt = timed(lambda: H.from_bytes(canon, out), reps=5)
+print("from_bytes n=2^24 scalars %8.3f ms  %8.2f G scalars/s  %7.1f GB/s (64 B/scalar)" % (dt * 1e3, n / dt / 1e9, 64 * n / dt / 1e9))
+nt = 1 << 18
+st = H.gen_b(5 * nt, dev)
+dt = timed(lambda: H.perm_trace(st), reps=3)
+print("perm_trace n=2^18 states  %8.3f ms  %8.2f Mperm/s  (67 x 160 B written per state: %.1f GB/s)" % (dt * 1e3, nt / dt / 1e6, 67 * 160 * nt / dt / 1e9))
