@@ -208,6 +208,10 @@ __device__ __forceinline__ void small_mds(F29 (&st)[5]) {
 __device__ __forceinline__ void fast_round(const int32_t *rec, bool full, F29 (&st)[5]) {
     // partial rounds: the constants of words 0..3 were pushed through the linear layers on the
     // host (hades252_amd/_derive.py), only word 4 receives one
+    // fetch the rescale factor now (scalar loads), ~1500 instructions before it is needed
+    int32_t kr[kNL];
+#pragma unroll
+    for (int k = 0; k < kNL; k++) kr[k] = rec[5 * kNL + k];
     if (full) {
 #pragma unroll
         for (int w = 0; w < 4; w++) add_lazy(st[w], rec + w * kNL);
@@ -220,7 +224,7 @@ __device__ __forceinline__ void fast_round(const int32_t *rec, bool full, F29 (&
         st[3] = sbox29(st[3]);
     }
     st[4] = sbox29(st[4]);
-    if (!full) st[4] = mont_mul_const(st[4], rec + 5 * kNL);
+    if (!full) st[4] = mont_mul_const(st[4], kr);
     small_mds(st);
 #pragma unroll
     for (int w = 0; w < 5; w++)
