@@ -4,15 +4,23 @@
 
 The library is built into ``hades252_amd/csrc/libhades252.so`` so that it travels with the source
 tree (it is git-ignored).  hipcc cross-compiles without a GPU.
+
+Staleness is decided by a content hash of the sources (kept in ``libhades252.so.stamp``), not by
+mtimes -- a copied tree does not preserve them.  Builds are serialised with a file lock and the
+library is replaced atomically, so several ranks of one job may call ``build()`` at once.
 """
 from __future__ import annotations
 
+import fcntl
+import hashlib
 import os
 import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libhades252.so")
+STAMP = LIB + ".stamp"
+LOCK = LIB + ".lock"
 SOURCES = ["hades252.hip"]
 DEPS = ["hades252.hip", "fr32.cuh", "staging.cuh", "hades_literal.cuh", "hades_fast.cuh",
         "hades_constants.inc", os.path.join("..", "..", "include", "hades252.h")]
@@ -21,24 +29,41 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-pth
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
+def source_hash() -> str:
+    h = hashlib.sha256(" ".join(FLAGS).encode())
     for d in DEPS:
-        p = os.path.join(CSRC, d)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(d.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def _fresh(want: str) -> bool:
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
+        return False
+    with open(STAMP) as f:
+        return f.read().strip() == want
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not _stale():
+    want = source_hash()
+    if not force and _fresh(want):
         return LIB
-    cmd = [HIPCC] + FLAGS + ["-o", LIB] + SOURCES
-    if verbose:
-        print("[hades252_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, cwd=CSRC, check=True)
+    with open(LOCK, "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _fresh(want):          # another process built it while we waited
+                return LIB
+            tmp = LIB + ".tmp.%d" % os.getpid()
+            cmd = [HIPCC] + FLAGS + ["-o", tmp] + SOURCES
+            if verbose:
+                print("[hades252_amd.build]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, cwd=CSRC, check=True)
+            os.replace(tmp, LIB)
+            with open(STAMP + ".tmp", "w") as f:
+                f.write(want + "\n")
+            os.replace(STAMP + ".tmp", STAMP)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
