@@ -2,31 +2,30 @@
 //
 // Same field elements as the reference's ScalarStrategy::perm (src/strategies.rs:140-157,
 // src/strategies/scalar.rs:23-49) -- hence the same bits after the final full reduction --
-// with ~10x fewer VALU instructions than the literal round structure:
+// with 13x fewer VALU instructions than the literal round structure:
 //
-//  1. Unsaturated radix 2^29, 9 (signed) limbs per element.  Measured on gfx950 (tools/ubench.hip):
-//     v_mad_u64_u32 issues at the same ~3.4 cycles/wave as v_addc_co_u32, so the cost of a
-//     big-integer product is its INSTRUCTION COUNT.  29-bit limbs leave 6 bits of headroom in a
-//     64-bit column, so a column of 9 products + 9 reduction terms needs no carry handling:
-//     every limb product is exactly one v_mad_u64_u32 accumulating in place.
-//  2. MDS with small integers.  The reference matrix is M[i][j] = 2^256/(i+j+5) mod p
+//  1. Unsaturated radix 2^29, 9 signed limbs per element.  Measured on gfx950 (tools/ubench*.hip):
+//     a 32x32+64 multiply-add (v_mad_i64_i32 / v_mad_u64_u32) issues at the same rate as a 64-bit
+//     add or shift (~4 cycles per wave per SIMD), so the cost of a big-integer product is its
+//     INSTRUCTION COUNT.  29-bit limbs leave headroom in a signed 64-bit column for 9 products + 8
+//     reduction terms + carry, so every limb product is exactly one multiply-add in place.
+//  2. Signed-digit Montgomery reduction interleaved with the product on ONE accumulator: p == 1
+//     (mod 2^29), so the quotient digit is just the low 29 bits of the accumulator.
+//  3. MDS with small integers.  The reference matrix is M[i][j] = 2^256/(i+j+5) mod p
 //     (loader semantics of src/mds_matrix.rs:18-40) = lam * C with C[i][j] = 360360/(i+j+5)
-//     < 2^17.  The kernel multiplies by C (9 mads per word instead of a 81+72 mad Montgomery
-//     product) and never applies lam: it is tracked as a known scale factor of the state.
-//  3. Scale tracking.  Neither lam, nor the 1/Rp of each Montgomery product (Rp = 2^261), nor the
+//     < 2^17.  The kernel multiplies by C (9 multiply-adds per word instead of a 153 multiply-add
+//     Montgomery product) and never applies lam: it is tracked as a known scale of the state.
+//  4. Scale tracking.  Neither lam, nor the 1/Rp of each Montgomery product (Rp = 2^261), nor the
 //     2^-29 of the one-limb reduction after each linear layer is ever applied; the running scale
 //     s_r is folded into the round constants on the host (hades252_amd/_derive.py).  In partial
 //     rounds one extra constant product K_r brings the S-boxed word back to the common scale.
 //     One product with FINAL_F at the end returns value * 2^256, which is then fully reduced --
 //     the unique in-memory BlsScalar.
-//  4. Every product and every linear-layer row runs on ONE 64-bit accumulator (finely integrated
-//     product scanning), so a product in flight needs its two operands, nine quotient digits and
-//     two accumulator registers instead of an 18-column array: the kernel fits 4+ waves per SIMD,
-//     which the VALU needs to reach its ~3.4-cycle issue rate for v_mad_u64_u32.
+//  5. Partial-round constants of words 0..3 are pushed through the linear layers on the host.
 //
-// Register budget: state 5 x 9 VGPRs + ~30 for the product in flight.
-// Constants are wave-uniform: scalar loads (SMEM) into SGPRs, consumed directly as
-// v_mad_u64_u32 operands.
+// Registers: state 5 x 9 VGPRs + ~35 for the product in flight (operands, nine quotient digits,
+// one accumulator -- no column array).  Constants are wave-uniform: scalar loads (SMEM) into
+// SGPRs, consumed directly as multiply-add operands.
 #pragma once
 #include "fr32.cuh"
 #include "staging.cuh"
