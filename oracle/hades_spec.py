@@ -99,12 +99,34 @@ def load_mds(blob: bytes) -> list[list[int]]:
 
 _CACHE: dict[str, object] = {}
 
+# How the blob bytes become constants.
+#   "from_raw"  (default, what the reference's code does): src/round_constants.rs:41 and
+#               src/mds_matrix.rs:33 hand each chunk to BlsScalar::from_raw, i.e. the chunk is a
+#               CANONICAL integer; since the generator wrote Montgomery limbs (HOWTO.md:45,104) the
+#               effective constants are howto * R.
+#   "howto"     the other reading (chunk = in-memory Montgomery limbs, constants = the HOWTO values).
+#               NOT what the code does; kept so that one run of the real crate can settle the
+#               question: perm([1;5])[0] is 0x71a5b804... under "from_raw" and 0x5221c7bb... under
+#               "howto" (SURVEY.md section 8(a) "Disambiguator").
+LOADER = "from_raw"
+
+
+def set_loader(mode: str) -> None:
+    global LOADER
+    assert mode in ("from_raw", "howto")
+    LOADER = mode
+    _CACHE.clear()
+
 
 def round_constants() -> list[int]:
     if "ark" not in _CACHE:
         blob = ark_blob()
         assert hashlib.sha256(blob).hexdigest() == ARK_SHA256, "regenerated ark.bin differs"
-        _CACHE["ark"] = load_round_constants(blob)
+        vals = load_round_constants(blob)
+        if LOADER == "howto":
+            vals = [v * R_INV % P for v in vals]
+            assert vals == howto_ark_values()
+        _CACHE["ark"] = vals
     return _CACHE["ark"]            # type: ignore[return-value]
 
 
@@ -112,7 +134,11 @@ def mds_matrix() -> list[list[int]]:
     if "mds" not in _CACHE:
         blob = mds_blob()
         assert hashlib.sha256(blob).hexdigest() == MDS_SHA256, "regenerated mds.bin differs"
-        _CACHE["mds"] = load_mds(blob)
+        m = load_mds(blob)
+        if LOADER == "howto":
+            m = [[v * R_INV % P for v in row] for row in m]
+            assert m == howto_mds_values()
+        _CACHE["mds"] = m
     return _CACHE["mds"]            # type: ignore[return-value]
 
 

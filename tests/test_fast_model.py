@@ -197,3 +197,18 @@ def test_schedule_tables_shape():
     for i in range(5):
         for j in range(5):
             assert lam * D.MDS_SMALL[i][j] % P == m[i][j]
+
+
+def test_other_loader_reading_is_one_flag_away(monkeypatch):
+    """If the real crate ever shows the 'howto' reading, the product tables regenerate with
+    HADES252_LOADER=howto; the scale-tracked schedule stays valid (lam = 1/L) -- checked here
+    value-level against the spec oracle in that mode."""
+    monkeypatch.setattr(D, "LOADER", "howto")
+    S.set_loader("howto")
+    try:
+        D.check_blobs()
+        vals = [3, 1, 4, 1, 5]
+        got = fast_perm_model([S.to_mont(v) for v in vals])
+        assert got == [S.to_mont(v) for v in S.perm(vals)]
+    finally:
+        S.set_loader("from_raw")
