@@ -231,10 +231,11 @@ __device__ __forceinline__ void fast_round(const int32_t *rec, bool full, F29 (&
         for (int k = 0; k < kNL; k++) limb_fence(st[w].l[k]);
 }
 
-// x (normalised, value in (-2p, p)) -> the fully reduced BlsScalar of x mod p
+// x = mont_mul_const(state word, FINAL_F): normalised, value in (-p - 2^250, 2^250]
+// -> the fully reduced BlsScalar of x mod p
 __device__ __forceinline__ Fr finalize(const F29 &x) {
-    // x + 2p in (0, 3p): carry-normalise (all limbs end non-negative), then two conditional
-    // subtractions of p in the saturated 8 x 32 form
+    // x + 2p lies in (p - 2^250, 2p + 2^250), below 2^256: carry-normalise (all limbs end
+    // non-negative), then two conditional subtractions of p in the saturated 8 x 32 form
     F29 y;
     int32_t carry = 0;
 #pragma unroll
