@@ -155,6 +155,64 @@ __global__ void __launch_bounds__(kBlock, 4) k_merkle4_level_fast(const uint8_t 
     wave_store_records<1>(parents, rec0, n_parents, slab, out);
 }
 
+// Batched fixed-length sponge over the permutation (the caller shape of dusk-poseidon's sponge
+// hash, reference README.md:9; that crate is NOT part of the reference tree, so the convention
+// -- capacity word, padding -- is a parameter and parity is pinned only to this repo's oracle).
+// Lane i hashes message i: state = [capacity, 0, 0, 0, 0]; every block of 4 scalars is added to
+// words 1..4 and followed by a permutation; pad_mode 1 appends a single 1 (then zeros) first.
+// Digest = word 1.
+__global__ void __launch_bounds__(kBlock, 4) k_sponge_fixed(const uint8_t *__restrict__ msgs, uint8_t *__restrict__ digests,
+                                                            size_t n_msgs, size_t msg_len, Fr capacity, int pad_mode) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<1>(lds);
+    const size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    const size_t me = rec0 + (threadIdx.x & (kWave - 1));
+    const bool live = me < n_msgs;
+    const uint4 *mine = reinterpret_cast<const uint4 *>(msgs) + (live ? me : 0) * msg_len * 2;
+    Fr one_mont;                               // 1 * 2^256 mod p
+    {
+        const uint32_t r1[8] = {0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau,
+                                0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u};
+#pragma unroll
+        for (int i = 0; i < 8; i++) one_mont.l[i] = r1[i];
+    }
+    Fr st[5];
+    st[0] = capacity;
+#pragma unroll
+    for (int w = 1; w < 5; w++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) st[w].l[i] = 0;
+    const size_t padded = msg_len + (pad_mode == 1 ? 1 : 0);
+    size_t blocks = (padded + 3) / 4;
+    if (blocks == 0) blocks = 1;
+#pragma unroll 1
+    for (size_t t = 0; t < blocks; t++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const size_t idx = 4 * t + k;
+            Fr v;
+#pragma unroll
+            for (int i = 0; i < 8; i++) v.l[i] = 0;
+            if (idx < msg_len) {
+                if (live) {
+                    uint4 lo = mine[2 * idx], hi = mine[2 * idx + 1];
+                    v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w;
+                    v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
+                }
+            } else if (idx == msg_len && pad_mode == 1) {
+                v = one_mont;
+            }
+            st[1 + k] = fr_add(st[1 + k], v);
+        }
+        Fr out[5];
+        fast_perm<5>(&d_fast, st, out, 0);
+#pragma unroll
+        for (int w = 0; w < 5; w++) st[w] = out[w];
+    }
+    Fr dig[1] = {st[1]};
+    wave_store_records<1>(digests, rec0, n_msgs, slab, dig);
+}
+
 __device__ __forceinline__ uint64_t splitmix_limb(uint64_t seed, uint64_t idx) {
     uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -591,6 +649,23 @@ int hades252_merkle4_level_dev(const void *d_children, void *d_parents, size_t n
     int rc = launch_merkle4_level_fast((const uint8_t *)d_children, (uint8_t *)d_parents, n_parents, tag, out_idx,
                                        (hipStream_t)stream);
     if (rc != HADES252_OK) return rc;
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
+int hades252_sponge_hash_dev(const void *d_msgs, size_t n_msgs, size_t msg_len, const uint64_t capacity_mont[4],
+                             int pad_mode, void *d_digests, void *stream) {
+    if (n_msgs == 0) return HADES252_OK;
+    if (d_digests == nullptr || capacity_mont == nullptr || (d_msgs == nullptr && msg_len > 0) ||
+        (pad_mode != 0 && pad_mode != 1) || n_msgs > kMaxLaunchRecords || misaligned(d_msgs) || misaligned(d_digests))
+        return HADES252_ERR_INVALID_ARG;
+    Fr cap;
+    for (int k = 0; k < 4; k++) {
+        cap.l[2 * k] = (uint32_t)capacity_mont[k];
+        cap.l[2 * k + 1] = (uint32_t)(capacity_mont[k] >> 32);
+    }
+    hipLaunchKernelGGL(k_sponge_fixed, dim3(blocks_for(n_msgs)), dim3(kBlock), lds_for(1), (hipStream_t)stream,
+                       (const uint8_t *)d_msgs, (uint8_t *)d_digests, n_msgs, msg_len, cap, pad_mode);
     HIP_TRY(hipGetLastError());
     return HADES252_OK;
 }

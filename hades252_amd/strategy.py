@@ -282,6 +282,24 @@ def merkle4_root(leaves_t, tag_mont: int, out_idx: int = 1, scratch=None):
     return root
 
 
+def sponge_hash(msgs_t, msg_len: int, capacity_mont: int, pad_mode: int = 1):
+    """Batched fixed-length sponge (include/hades252.h): msgs_t holds n messages of msg_len
+    scalars; returns [n, 4] int64 digests (word 1 of the final state)."""
+    import torch
+    if msg_len > 0:
+        ptr, n_scalars, dev = _dev_buffer(msgs_t, 32, "sponge_hash")
+        if n_scalars % msg_len != 0:
+            raise ValueError("sponge_hash: buffer is not a whole number of messages")
+        n = n_scalars // msg_len
+    else:
+        raise ValueError("sponge_hash: msg_len must be positive for a tensor batch")
+    out = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_sponge_hash_dev(ptr, n, msg_len, _tag_arr(capacity_mont), pad_mode,
+                                                  out.data_ptr(), _stream_ptr(dev)), "sponge_hash")
+    return out
+
+
 GEN_SEED = 0x4861646573323532
 
 

@@ -115,6 +115,16 @@ size_t hades252_merkle4_scratch_bytes(size_t n_leaves);
 int hades252_merkle4_root_dev(const void *d_leaves, size_t n_leaves, void *d_scratch, size_t scratch_bytes,
                               const uint64_t tag_mont[4], int out_idx, void *d_root, void *stream);
 
+/* ---- batched fixed-length sponge (caller shape of dusk-poseidon's sponge hash, README.md:9) ----
+ * d_msgs: n_msgs messages of msg_len scalars each (Montgomery limbs, contiguous: message i at scalar
+ * offset i*msg_len).  state = [capacity, 0, 0, 0, 0]; each block of 4 scalars is added to words 1..4,
+ * then permuted; pad_mode 1 first appends a single scalar 1 (then zeros), pad_mode 0 zero-fills;
+ * at least one permutation is always applied.  Digest i = word 1 (32 B) -> d_digests[i].
+ * dusk-poseidon is not part of the reference tree: capacity and padding are parameters and this
+ * entry point's parity is pinned to this repo's oracle only. */
+int hades252_sponge_hash_dev(const void *d_msgs, size_t n_msgs, size_t msg_len, const uint64_t capacity_mont[4],
+                             int pad_mode, void *d_digests, void *stream);
+
 /* ---- synthetic inputs and digests (benchmark / verification plumbing) --------------------- */
 /* Generator B: scalar e (global element index first_elem + k) gets 4 splitmix64 limbs, top limb
  * masked to 62 bits (always < p); see DESIGN.md.  Stateless, so shards generate independently. */

@@ -351,6 +351,36 @@ void hades_oracle_merkle4_level(const uint64_t *children, uint64_t *parents, siz
     for (int t = 1; t < n_threads; t++) pthread_join(th[t], NULL);
 }
 
+/* ---- fixed-length sponge: state = [cap,0,0,0,0]; add 4 scalars to words 1..4, perm; pad_mode 1
+ * appends a single 1 first; at least one perm.  Digest = word 1.  (Caller shape of
+ * dusk-poseidon, which is not part of the reference tree: convention = parameters.) ---------- */
+void hades_oracle_sponge(const uint64_t *msgs, size_t n_msgs, size_t msg_len, const uint64_t *cap_mont,
+                         int pad_mode, uint64_t *digests) {
+    hades_oracle_init();
+    const uint64_t one_raw[4] = {1, 0, 0, 0};
+    const fr_t one = fr_from_raw(one_raw);
+    size_t padded = msg_len + (pad_mode == 1 ? 1 : 0);
+    size_t blocks = (padded + 3) / 4;
+    if (blocks == 0) blocks = 1;
+    for (size_t i = 0; i < n_msgs; i++) {
+        fr_t st[WIDTH];
+        memset(st, 0, sizeof st);
+        memcpy(st[0].l, cap_mont, 32);
+        for (size_t t = 0; t < blocks; t++) {
+            for (int k = 0; k < 4; k++) {
+                size_t idx = 4 * t + k;
+                fr_t v;
+                memset(&v, 0, sizeof v);
+                if (idx < msg_len) memcpy(v.l, msgs + 4 * (i * msg_len + idx), 32);
+                else if (idx == msg_len && pad_mode == 1) v = one;
+                st[1 + k] = fr_add(st[1 + k], v);
+            }
+            hades_oracle_perm((uint64_t *)st);
+        }
+        memcpy(digests + 4 * i, st[1].l, 32);
+    }
+}
+
 /* ---- field-op exports for unit tests -------------------------------------------------- */
 void hades_oracle_fr_add(const uint64_t *a, const uint64_t *b, uint64_t *out) {
     fr_t x, y; memcpy(x.l, a, 32); memcpy(y.l, b, 32); x = fr_add(x, y); memcpy(out, x.l, 32);

@@ -258,3 +258,20 @@ def merkle4_root(leaves: list[int], tag: int = 15, out_idx: int = 1) -> int:
         assert len(level) % 4 == 0
         level = [merkle4_node(level[i:i + 4], tag, out_idx) for i in range(0, len(level), 4)]
     return level[0]
+
+
+# --------------------------------------------------------------------------------------
+# Fixed-length sponge (convention parameters: see include/hades252.h); canonical integers
+# --------------------------------------------------------------------------------------
+def sponge_hash(msg: list[int], capacity: int, pad_mode: int = 1) -> int:
+    padded = list(msg) + ([1] if pad_mode == 1 else [])
+    if not padded:
+        padded = [0]
+    while len(padded) % 4:
+        padded.append(0)
+    st = [capacity % P, 0, 0, 0, 0]
+    for t in range(0, len(padded), 4):
+        for k in range(4):
+            st[1 + k] = (st[1 + k] + padded[t + k]) % P
+        st = perm(st)
+    return st[1]

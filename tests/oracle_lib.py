@@ -108,6 +108,15 @@ class Oracle:
             level = self.merkle4_level(level, tag_mont, out_idx)
         return level
 
+    def sponge(self, msgs, msg_len, cap_mont, pad_mode=1):
+        m = np.ascontiguousarray(msgs, dtype=np.uint64)
+        n = m.size // (4 * msg_len) if msg_len else 0
+        out = np.zeros(4 * n, dtype=np.uint64)
+        cap = np.array(limbs_of(cap_mont), dtype=np.uint64)
+        self.l.hades_oracle_sponge(_p(m), ctypes.c_size_t(n), ctypes.c_size_t(msg_len), _p(cap),
+                                   ctypes.c_int(pad_mode), _p(out))
+        return out
+
     def from_bytes(self, b32):
         buf = (ctypes.c_uint8 * 32)(*b32)
         out = np.zeros(4, dtype=np.uint64)

@@ -476,3 +476,18 @@ def test_exhaustive_edge_tuples(torch_cuda, H, oracle):
     buf = to_dev(torch, inp)
     H.ScalarStrategy(2).perm(buf)
     assert (to_host(buf) == oracle.perm_batch(inp)).all()
+
+
+def test_sponge_hash(torch_cuda, H, oracle):
+    """Batched fixed-length sponge over the permutation vs the oracle (convention parameters;
+    dusk-poseidon itself is outside the reference tree)."""
+    torch = torch_cuda
+    cap = S.to_mont(1 << 64)
+    for length in (1, 2, 3, 4, 5, 7, 8, 9, 16):
+        for pad in (0, 1):
+            n = 1000 if length < 9 else 130
+            msgs = oracle.gen_b(length * 977 + pad, n * length)
+            got = H.sponge_hash(to_dev(torch, msgs), length, cap, pad)
+            assert (to_host(got) == oracle.sponge(msgs, length, cap, pad)).all(), (length, pad)
+    with pytest.raises(ValueError):
+        H.sponge_hash(to_dev(torch, oracle.gen_b(0, 10)), 3, cap, 1)

@@ -208,3 +208,18 @@ def test_loader_semantics_disambiguator():
     finally:
         S.set_loader("from_raw")
     assert S.perm([1] * 5)[0] == 0x71a5b8040ed5c21f5900c854f34748e89dfb577514b9bd816e62e1b3e3f039c3
+
+
+def test_sponge_c_oracle_vs_spec(oracle):
+    rng = random.Random(4)
+    cap = 1 << 64
+    for length in (1, 3, 4, 5, 8, 9):
+        for pad in (0, 1):
+            msgs = [[rng.randrange(P) for _ in range(length)] for _ in range(3)]
+            flat = np.array([l for m in msgs for v in m for l in limbs_of(S.to_mont(v))], dtype=np.uint64)
+            got = oracle.sponge(flat, length, S.to_mont(cap), pad).reshape(-1, 4)
+            for i, m in enumerate(msgs):
+                assert S.from_mont(int_of(got[i])) == S.sponge_hash(m, cap, pad)
+    # padding 1 makes a message and its zero-extended version hash differently
+    assert S.sponge_hash([7], cap, 1) != S.sponge_hash([7, 0], cap, 1)
+    assert S.sponge_hash([7], cap, 0) == S.sponge_hash([7, 0], cap, 0)

@@ -73,3 +73,11 @@ nt = 1 << 18
 st = H.gen_b(5 * nt, dev)
 dt = timed(lambda: H.perm_trace(st), reps=3)
 print("perm_trace n=2^18 states  %8.3f ms  %8.2f Mperm/s  (67 x 160 B written per state: %.1f GB/s)" % (dt * 1e3, nt / dt / 1e6, 67 * 160 * nt / dt / 1e9))
+
+print("== batched fixed-length sponge (rate 4, pad with 1)")
+cap = (1 << 64) * ((1 << 256) % 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001) % 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+for length, nmsg in ((3, 1 << 22), (4, 1 << 22), (16, 1 << 20)):
+    msgs = H.gen_b(nmsg * length, dev)
+    dt = timed(lambda: H.sponge_hash(msgs, length, cap, 1), reps=3)
+    perms = nmsg * ((length + 1 + 3) // 4)
+    print("len=%-2d n=2^%-2d %8.3f ms  %8.2f Mhash/s  %8.2f Mperm/s" % (length, nmsg.bit_length() - 1, dt * 1e3, nmsg / dt / 1e6, perms / dt / 1e6))
