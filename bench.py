@@ -171,7 +171,7 @@ def main():
         "metric": "Hades252 permutations/sec (WIDTH=5, BLS12-381 Fr)",
         "value": value, "unit": "permutations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "int64", "data": "synthetic",
         "config": {"workload": "2^%d independent WIDTH=5 permutations per GPU, in place in HBM "
                                "(BASELINE configs[2]; generator B, Montgomery-limb AoS records)"
                                % (n.bit_length() - 1) if n & (n - 1) == 0 else "%d permutations per GPU" % n,
