@@ -7,9 +7,14 @@
 A step is one pass of the hot path (the batched `ScalarStrategy::perm`, through the C ABI
 `hades252_perm_batch_dev`) over one synthetic batch already resident in HBM: 2^26 independent
 width-5 permutations per GPU (BASELINE.json configs[2]; 10 GiB in place), generated on device by
-the counter-based generator B.  With N GPUs every rank owns its own 2^26 permutations (weak
-scaling, global element indices are disjoint); there is no data-path collective.  Rank 0 prints
-ONE JSON line.
+the counter-based generator B.  With N GPUs every rank owns its own batch (weak scaling, global
+element indices are disjoint; at N = 8 the default is 2^27 per GPU = BASELINE.json configs[4], 2^30
+in total); there is no data-path collective.  Rank 0 prints ONE JSON line.
+
+Launching: under torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this process is one
+rank.  Without it, `--gpus N` with N > 1 makes this process a LAUNCHER: it spawns N rank processes
+(one per GPU, rendezvous on 127.0.0.1) before anything touches the GPU, waits for them, and exits
+with their status -- the ranks do the work and rank 0 prints the line.
 
 Also in the line:
   roofline      the dominant kernel (k_perm_fast) against the HBM roofline the metric names:
@@ -94,19 +99,74 @@ def cpu_baseline_and_check(H, torch, device, n_sample: int):
     }, ok
 
 
+def verify_sample(H, torch, states, first_perm: int, n: int, k: int) -> bool:
+    """Bit-exact check of k states of THIS rank's shard (first k/2 + k/2 strided) against the oracle.
+    Runs before the timed region on the freshly generated inputs; the oracle is the checker only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib
+    orc = oracle_lib.load()
+    k = max(2, min(k, n))
+    idx = np.unique(np.concatenate([np.arange(k // 2), np.arange(0, n, max(1, n // (k // 2)))[: k // 2]]))
+    tidx = torch.from_numpy(idx).to(states.device)
+    sample = states[tidx].contiguous()
+    inp = sample.cpu().numpy().view(np.uint64).reshape(-1).copy()
+    # inputs are what generator B defines for these global indices
+    e0 = 5 * (first_perm + int(idx[-1]))
+    if not (inp[-20:] == orc.gen_b(e0, 5)).all():
+        return False
+    H.ScalarStrategy().perm(sample)
+    got = sample.cpu().numpy().view(np.uint64).reshape(-1)
+    return bool((got == orc.perm_batch(inp, min(usable_cores(), 8))).all())
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without torchrun: spawn the N ranks.  This process never touches the GPU
+    (a process that has initialised HIP must not be replaced or forked into GPU work on this pool)."""
+    import socket
+    import subprocess
+    from hades252_amd import build
+    build.build(verbose=False)          # once, so the ranks do not race to compile
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--perms-per-gpu", type=int, default=1 << 26)
+    ap.add_argument("--perms-per-gpu", type=int, default=0,
+                    help="default: 2^26 (BASELINE configs[2]); 2^27 at 8 GPUs (configs[4]: 2^30 in total)")
     ap.add_argument("--kernel", type=int, default=0, help="0 default (fast), 1 literal, 2 fast")
     ap.add_argument("--cpu-sample", type=int, default=1 << 20)
+    ap.add_argument("--verify-sample", type=int, default=2048, help="states per rank checked against the oracle (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     # test hooks for boxes with fewer GPUs than ranks (control-flow check of the N>1 path only)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (testing)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
 
     import torch
     from hades252_amd import build, sharding
@@ -114,10 +174,7 @@ def main():
     from hades252_amd import strategy as H
 
     rank, local_rank, world = sharding.env_world()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a torch.distributed launch with %d ranks" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: hades252_amd has no CPU fallback")
     dev_index = 0 if args.single_device else local_rank
@@ -126,11 +183,14 @@ def main():
     if world > 1:
         sharding.init_process_group(args.dist_backend)
 
-    n = args.perms_per_gpu
+    n = args.perms_per_gpu or ((1 << 27) if world == 8 else (1 << 26))
     first_perm, _ = sharding.weak_shard(rank, n)
     strat = H.ScalarStrategy(args.kernel)
     states = torch.empty((n, 5, 4), dtype=torch.int64, device=device)
     H.gen_b(5 * n, device, first_elem=5 * first_perm, out=states.view(-1, 4))
+    rank_ok = True
+    if world > 1:
+        rank_ok = verify_sample(H, torch, states, first_perm, n, args.verify_sample)
 
     for _ in range(args.warmup):
         strat.perm(states)
@@ -151,37 +211,49 @@ def main():
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
     kernel_ms_max = sharding.reduce_max(kernel_ms, device)
+    per_rank_ms = sharding.gather_floats(kernel_ms, device)
+    all_ok = sharding.reduce_min_int(1 if rank_ok else 0, device) == 1
     digest = sharding.combine_digests(H.digest(states, first_index=20 * first_perm), device)
 
     if rank != 0:
+        if not rank_ok:
+            raise SystemExit("rank %d: GPU output differs from the CPU oracle" % rank)
         return
     total_perms = n * world * args.steps
     value = total_perms / elapsed
     achieved = ALGO_BYTES_PER_PERM * n / (kernel_ms_max * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
             rec = json.load(open(tpath))
-            if rec.get("perms_per_launch") == n:
+            if rec.get("perms_per_launch") == n and rec.get("kernel_source_hash") == build.source_hash():
                 traffic = rec.get("hbm_bytes_per_launch")
+                traffic_source = ("NOT measured in this run: replayed from the committed rocprofv3 PMC passes "
+                                  "(profiles/hbm_traffic.json, same kernel source hash %s)" % build.source_hash()[:12])
         except Exception:
             traffic = None
+    pow2 = n & (n - 1) == 0
     out = {
         "metric": "Hades252 permutations/sec (WIDTH=5, BLS12-381 Fr)",
         "value": value, "unit": "permutations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-        "config": {"workload": "2^%d independent WIDTH=5 permutations per GPU, in place in HBM "
-                               "(BASELINE configs[2]; generator B, Montgomery-limb AoS records)"
-                               % (n.bit_length() - 1) if n & (n - 1) == 0 else "%d permutations per GPU" % n,
-                   "perms_per_gpu": n, "state_bytes": 160, "kernel": "k_perm_fast" if args.kernel != 1 else "k_states_literal",
+        "config": {"workload": ("2^%d independent WIDTH=5 permutations per GPU, in place in HBM (BASELINE %s; generator "
+                                "B, Montgomery-limb AoS records)"
+                                % (n.bit_length() - 1, "configs[4]: 2^30 over 8 GPUs" if (world == 8 and n == 1 << 27)
+                                   else "configs[2]")) if pow2 else "%d permutations per GPU" % n,
+                   "perms_per_gpu": n, "total_perms_per_step": n * world, "state_bytes": 160,
+                   "kernel": "k_perm_fast" if args.kernel != 1 else "k_states_literal",
                    "sharding": "contiguous range per rank, no collective"},
+        "per_gpu": {"value": value / world, "unit": "permutations/s",
+                    "kernel_ms_per_rank": per_rank_ms,
+                    "perms_per_s_per_rank": [n / (ms * 1e-3) for ms in per_rank_ms]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel_ms": kernel_ms_max, "algorithmic_bytes_per_perm": ALGO_BYTES_PER_PERM,
                      "note": "HBM traffic equals the algorithmic bytes; the kernel is VALU-issue bound "
-                             "(~95 k instructions per 320 B), see valu_issue and DESIGN.md"},
+                             "(~89 k instructions per 320 B), see valu_issue and DESIGN.md"},
         "valu_issue": {"bound": "v_mad_u64_u32 issue", "mads_per_perm": MADS_PER_PERM,
                        "achieved": MADS_PER_PERM * n / (kernel_ms_max * 1e-3) / 64 / 1e9,
                        "peak": VALU_PEAK_G_WAVE_INSTR, "unit": "G wave-instr/s",
@@ -193,14 +265,17 @@ def main():
                                "(kernel time x 2.4 GHz peak clock)"},
         "digest": ["%016x" % d for d in digest],
     }
+    if world > 1:
+        out["parity_vs_cpu_sample"] = all_ok
+        out["parity_sample"] = "%d states of every rank's shard vs the CPU oracle, AND over ranks" % args.verify_sample
     if world == 1 and not args.no_cpu_baseline:
         cb, ok = cpu_baseline_and_check(H, torch, device, args.cpu_sample)
         out["cpu_baseline"] = cb
         out["parity_vs_cpu_sample"] = ok
-        if not ok:
-            print(json.dumps(out))
-            raise SystemExit("GPU output differs from the CPU oracle")
-    print(json.dumps(out))
+        all_ok = ok
+    print(json.dumps(out), flush=True)
+    if not all_ok:
+        raise SystemExit("GPU output differs from the CPU oracle")
 
 
 if __name__ == "__main__":

@@ -16,6 +16,7 @@ ERR_HIP = -2
 ERR_NOT_CANONICAL = -3
 ERR_NO_DEVICE = -4
 ERR_SCRATCH = -5
+ERR_OUT_OF_CONSTANTS = -6
 
 KERNEL_DEFAULT = 0
 KERNEL_LITERAL = 1
@@ -34,7 +35,12 @@ SIGNATURES = {
     "hades252_perm_batch_dev_ex": (c_int, [c_void_p, c_size_t, c_void_p, c_int]),
     "hades252_perm_batch_multi": (c_int, [c_void_p, c_size_t, c_int]),
     "hades252_perm_trace_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hades252_perm_trace_dev_ex": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
     "hades252_add_round_key_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
+    "hades252_add_round_key_at_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
+    "hades252_apply_full_round_at_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
+    "hades252_apply_partial_round_at_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
+    "hades252_fr_op_dev": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "hades252_quintic_s_box_dev": (c_int, [c_void_p, c_size_t, c_void_p]),
     "hades252_mul_matrix_dev": (c_int, [c_void_p, c_size_t, c_void_p]),
     "hades252_apply_full_round_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
@@ -46,6 +52,8 @@ SIGNATURES = {
     "hades252_merkle4_root_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, POINTER(c_uint64), c_int,
                                           c_void_p, c_void_p]),
     "hades252_sponge_hash_dev": (c_int, [c_void_p, c_size_t, c_size_t, POINTER(c_uint64), c_int, c_void_p, c_void_p]),
+    "hades252_sponge_hash_var_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_uint64), c_int, c_void_p,
+                                             c_void_p]),
     "hades252_gen_b_dev": (c_int, [c_void_p, c_uint64, c_size_t, c_uint64, c_void_p]),
     "hades252_gen_a_dev": (c_int, [c_void_p, c_uint64, c_size_t, c_void_p]),
     "hades252_digest_dev": (c_int, [c_void_p, c_uint64, c_size_t, c_void_p, c_void_p]),

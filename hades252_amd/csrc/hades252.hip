@@ -21,13 +21,20 @@ using namespace hades;
 // ------------------------------------------------------------------------------------------
 // constant tables (code-object globals: one copy per device, loaded with the module)
 // ------------------------------------------------------------------------------------------
-__device__ const uint32_t d_ark_mont[HADES_N_ARK_USED][8] = HADES_ARK_MONT_INIT;
+// all 960 ROUND_CONSTANTS (src/round_constants.rs:18): perm() consumes the first 335, the trait's
+// add_round_key / apply_*_round accept any cursor (src/strategies.rs:33-41)
+__device__ const uint32_t d_ark_mont[HADES_N_ARK][8] = HADES_ARK_MONT_INIT;
 __device__ const uint32_t d_mds_mont[25][8] = HADES_MDS_MONT_INIT;
 // R^2 mod p (from_raw / from_bytes multiplier) and 1 (to_bytes multiplier), 8 x u32
 __device__ const uint32_t d_r2[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu,
                                      0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
 
 __device__ const FastTables d_fast = {HADES_FAST_ROUND_INIT, HADES_FAST_FINAL_F};
+// trace kernel: U_r with mont(X_after_round_r, U_r) = x * 2^256
+__device__ const int32_t d_trace_u[67][16] = HADES_FAST_TRACE_U_INIT;
+// generic radix-2^29 field ops (hades252_fr_op_dev)
+__device__ const int32_t d_rp_mod_p[16] = HADES_RP_MOD_P29;
+__device__ const int32_t d_rp2_over_r[16] = HADES_RP2_OVER_R29;
 
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
@@ -43,7 +50,7 @@ __device__ __forceinline__ uint8_t *wave_slab(uint8_t *lds) {
 enum Op { OP_PERM = 0, OP_ARK, OP_MDS, OP_FULL, OP_PARTIAL };
 
 template <int OP>
-__global__ void __launch_bounds__(kBlock) k_states_literal(uint8_t *__restrict__ states, size_t n, int round) {
+__global__ void __launch_bounds__(kBlock) k_states_literal(uint8_t *states, size_t n, int cursor) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *slab = wave_slab<5>(lds);
     size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
@@ -51,15 +58,16 @@ __global__ void __launch_bounds__(kBlock) k_states_literal(uint8_t *__restrict__
     wave_load_records<5>(states, rec0, n, slab, st);
     LiteralView V{d_ark_mont, d_mds_mont};
     if constexpr (OP == OP_PERM) lit_perm(V, st);
-    if constexpr (OP == OP_ARK) lit_add_round_key(V, round, st);
+    if constexpr (OP == OP_ARK) lit_add_round_key(V, cursor, st);
     if constexpr (OP == OP_MDS) lit_mul_matrix(V, st);
-    if constexpr (OP == OP_FULL) lit_full_round(V, round, st);
-    if constexpr (OP == OP_PARTIAL) lit_partial_round(V, round, st);
+    if constexpr (OP == OP_FULL) lit_full_round(V, cursor, st);
+    if constexpr (OP == OP_PARTIAL) lit_partial_round(V, cursor, st);
     wave_store_records<5>(states, rec0, n, slab, st);
 }
 
 // Per-round trace: the state after every round (what the PLONK gadget needs as witnesses,
 // reference src/strategies/gadget.rs:41-133), round-major: trace[r] is a whole AoS batch.
+// Literal variant (the reference's schedule; parity anchor for the fast one).
 __global__ void __launch_bounds__(kBlock) k_perm_trace_literal(const uint8_t *__restrict__ states,
                                                                uint8_t *__restrict__ trace, size_t n) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -71,14 +79,78 @@ __global__ void __launch_bounds__(kBlock) k_perm_trace_literal(const uint8_t *__
 #pragma unroll 1
     for (int r = 0; r < 67; r++) {
         if (r < 4 || r >= 63)
-            lit_full_round(V, r, st);
+            lit_full_round(V, 5 * r, st);
         else
-            lit_partial_round(V, r, st);
+            lit_partial_round(V, 5 * r, st);
         wave_store_records<5>(trace + (size_t)r * n * 160, rec0, n, slab, st);
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_sbox(uint8_t *__restrict__ scalars, size_t n) {
+// Scale-tracked trace (the shipped one): the rounds of k_perm_fast; after each round every word is
+// brought back to the in-memory BlsScalar with ONE constant product (U_r = 2^256 * Rp / s_{r+1},
+// hades252_amd/_derive.py) and a full reduction -- 5 extra products per round instead of the literal
+// schedule's 28 / 40 full-width products.
+__global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__restrict__ states,
+                                                               uint8_t *__restrict__ trace, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<5>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    F29 st[5];
+    {
+        Fr in[5];
+        wave_load_records<5>(states, rec0, n, slab, in);
+#pragma unroll
+        for (int w = 0; w < 5; w++) st[w] = to_f29(in[w]);
+    }
+#pragma unroll 1
+    for (int r = 0; r < 67; r++) {
+        fast_round(d_fast.round[r], r < 4 || r >= 63, st);
+        const int32_t *u = d_trace_u[r];
+#pragma unroll
+        for (int w = 0; w < 5; w++) slab_put<5>(slab, w, finalize(mont_mul_const(st[w], u)));
+        slab_flush<5>(trace + (size_t)r * n * 160, rec0, n, slab);
+    }
+}
+
+// Generic batched BlsScalar operations (reference call sites src/strategies/scalar.rs:28,33,44;
+// src/round_constants.rs:41): out[i] = a[i] (op) b[i] on Montgomery limbs, fully reduced.
+// IMPL 0: the saturated 8 x u32 CIOS arithmetic of fr32.cuh (what the literal kernels use);
+// IMPL 1: the radix-2^29 signed-limb arithmetic of the shipped kernel (to_f29, mont_fips, finalize).
+// These exist so that tests can drive BOTH device arithmetics through the computations that produced
+// the reference's constant blobs (tests/test_gpu_blob_kat.py), and as a13's batched surface.
+enum FrOp { FR_ADD = 0, FR_MUL = 1, FR_SQUARE = 2, FR_FROM_RAW = 3 };
+template <int IMPL>
+__global__ void __launch_bounds__(kBlock) k_fr_op(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, int op) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<1>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr x[1], y[1];
+    wave_load_records<1>(a, rec0, n, slab, x);
+    if (op == FR_ADD || op == FR_MUL) {
+        wave_load_records<1>(b, rec0, n, slab, y);
+    } else if (op == FR_SQUARE) {
+        y[0] = x[0];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) y[0].l[i] = d_r2[i];
+    }
+    Fr r[1];
+    if constexpr (IMPL == 0) {
+        r[0] = (op == FR_ADD) ? fr_add(x[0], y[0]) : fr_mul(x[0], y[0]);
+    } else {
+        F29 xa = to_f29(x[0]), yb = to_f29(y[0]);
+        if (op == FR_ADD) {
+            add_lazy(xa, yb.l);                                    // limbs < 2^30
+            r[0] = finalize(mont_mul_const(xa, d_rp_mod_p));       // (a + b) * Rp / Rp
+        } else {
+            F29 t = (op == FR_SQUARE) ? mont_sqr(xa) : mont_mul(xa, yb);   // a b / Rp
+            r[0] = finalize(mont_mul_const(t, d_rp2_over_r));      // * (Rp^2 / 2^256) / Rp = a b / 2^256
+        }
+    }
+    wave_store_records<1>(out, rec0, n, slab, r);
+}
+
+__global__ void __launch_bounds__(kBlock) k_sbox(uint8_t *scalars, size_t n) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *slab = wave_slab<1>(lds);
     size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
@@ -88,9 +160,9 @@ __global__ void __launch_bounds__(kBlock) k_sbox(uint8_t *__restrict__ scalars, 
     wave_store_records<1>(scalars, rec0, n, slab, st);
 }
 
-// canonical bytes <-> Montgomery limbs (32 B each way, one scalar per lane)
-__global__ void __launch_bounds__(kBlock) k_from_bytes(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
-                                                       size_t n, int *bad_count) {
+// canonical bytes <-> Montgomery limbs (32 B each way, one scalar per lane).  `out` may be `in`
+// (the host byte path converts in place): every wave loads its 64 records before storing them.
+__global__ void __launch_bounds__(kBlock) k_from_bytes(const uint8_t *in, uint8_t *out, size_t n, int *bad_count) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *slab = wave_slab<1>(lds);
     size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
@@ -111,7 +183,7 @@ __global__ void __launch_bounds__(kBlock) k_from_bytes(const uint8_t *__restrict
     wave_store_records<1>(out, rec0, n, slab, st);
 }
 
-__global__ void __launch_bounds__(kBlock) k_to_bytes(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, size_t n) {
+__global__ void __launch_bounds__(kBlock) k_to_bytes(const uint8_t *in, uint8_t *out, size_t n) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *slab = wave_slab<1>(lds);
     size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
@@ -130,7 +202,7 @@ __global__ void __launch_bounds__(kBlock) k_to_bytes(const uint8_t *__restrict__
 #ifndef HADES_FAST_MINW
 #define HADES_FAST_MINW 4
 #endif
-__global__ void __launch_bounds__(kBlock, HADES_FAST_MINW) k_perm_fast(uint8_t *__restrict__ states, size_t n) {
+__global__ void __launch_bounds__(kBlock, HADES_FAST_MINW) k_perm_fast(uint8_t *states, size_t n) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *slab = wave_slab<5>(lds);
     size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
@@ -155,20 +227,52 @@ __global__ void __launch_bounds__(kBlock, 4) k_merkle4_level_fast(const uint8_t 
     wave_store_records<1>(parents, rec0, n_parents, slab, out);
 }
 
-// Batched fixed-length sponge over the permutation (the caller shape of dusk-poseidon's sponge
-// hash, reference README.md:9; that crate is NOT part of the reference tree, so the convention
-// -- capacity word, padding -- is a parameter and parity is pinned only to this repo's oracle).
-// Lane i hashes message i: state = [capacity, 0, 0, 0, 0]; every block of 4 scalars is added to
-// words 1..4 and followed by a permutation; pad_mode 1 appends a single 1 (then zeros) first.
-// Digest = word 1.
-__global__ void __launch_bounds__(kBlock, 4) k_sponge_fixed(const uint8_t *__restrict__ msgs, uint8_t *__restrict__ digests,
-                                                            size_t n_msgs, size_t msg_len, Fr capacity, int pad_mode) {
+// Batched sponge over the permutation (the caller shape of dusk-poseidon's sponge hash, reference
+// README.md:9; that crate is NOT part of the reference tree, so the convention -- capacity word,
+// padding -- is a parameter and parity is pinned only to this repo's oracle: CONVENTION UNPINNED).
+// Lane i hashes message i = scalars[off_i .. off_i + len_i): state = [capacity, 0, 0, 0, 0]; every block
+// of 4 scalars is added to words 1..4 and followed by a permutation; pad_mode 1 appends a single 1
+// (then zeros) first; at least one permutation.  Digest = word 1.
+//   * variable length: `offsets` / `lengths` per message (NULL: message i = [i*fixed_len, (i+1)*fixed_len));
+//     every lane runs to the block-wide maximum block count and latches its digest after its own last
+//     block (later permutations of that lane work on don't-care data).
+//   * message blocks are staged through the wave's LDS slab: 8 lanes fetch the 128 contiguous bytes of one
+//     message block, 8 messages per load instruction -- no lane walks HBM with a message-sized stride.
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    uint32_t lo = __shfl((uint32_t)v, src, kWave), hi = __shfl((uint32_t)(v >> 32), src, kWave);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__global__ void __launch_bounds__(kBlock, 3) k_sponge(const uint8_t *__restrict__ scalars,
+                                                      const uint64_t *__restrict__ offsets,
+                                                      const uint64_t *__restrict__ lengths,
+                                                      uint8_t *__restrict__ digests, size_t n_msgs, size_t fixed_len,
+                                                      Fr capacity, int pad_mode) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t *slab = wave_slab<1>(lds);
+    __shared__ unsigned long long wave_max[kWavesPerBlock];
+    uint8_t *slab = wave_slab<4>(lds);
+    constexpr int kRec = lds_rec_bytes(4);
+    const int lane = threadIdx.x & (kWave - 1);
     const size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
-    const size_t me = rec0 + (threadIdx.x & (kWave - 1));
+    const size_t me = rec0 + lane;
     const bool live = me < n_msgs;
-    const uint4 *mine = reinterpret_cast<const uint4 *>(msgs) + (live ? me : 0) * msg_len * 2;
+    const uint64_t off = live ? (offsets != nullptr ? offsets[me] : (uint64_t)me * fixed_len) : 0;
+    const uint64_t len = live ? (lengths != nullptr ? lengths[me] : (uint64_t)fixed_len) : 0;
+    uint64_t blocks = (len + (pad_mode == 1 ? 1 : 0) + 3) / 4;
+    if (blocks == 0) blocks = 1;
+    if (!live) blocks = 0;
+    // block-uniform trip count (the staging below uses block-wide barriers)
+    uint64_t mx = blocks;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        uint64_t other = shfl_u64(mx, lane ^ o);
+        mx = other > mx ? other : mx;
+    }
+    if (lane == 0) wave_max[threadIdx.x / kWave] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; w++) mx = wave_max[w] > mx ? wave_max[w] : mx;
+
     Fr one_mont;                               // 1 * 2^256 mod p
     {
         const uint32_t r1[8] = {0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau,
@@ -182,35 +286,39 @@ __global__ void __launch_bounds__(kBlock, 4) k_sponge_fixed(const uint8_t *__res
     for (int w = 1; w < 5; w++)
 #pragma unroll
         for (int i = 0; i < 8; i++) st[w].l[i] = 0;
-    const size_t padded = msg_len + (pad_mode == 1 ? 1 : 0);
-    size_t blocks = (padded + 3) / 4;
-    if (blocks == 0) blocks = 1;
+    Fr dig = st[1];
 #pragma unroll 1
-    for (size_t t = 0; t < blocks; t++) {
+    for (uint64_t t = 0; t < mx; t++) {
+        // stage block t of all 64 messages: lane = (message 8k + lane/8, 16-byte part lane%8)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int m = 8 * k + (lane >> 3), part = lane & 7;
+            const uint64_t moff = shfl_u64(off, m), mlen = shfl_u64(len, m);
+            const uint64_t idx = 4 * t + (part >> 1);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < mlen) v = *reinterpret_cast<const uint4 *>(scalars + (moff + idx) * 32 + (part & 1) * 16);
+            *reinterpret_cast<uint4 *>(slab + m * kRec + part * 16) = v;
+        }
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const size_t idx = 4 * t + k;
+            const uint4 *p = reinterpret_cast<const uint4 *>(slab + lane * kRec + k * 32);
+            uint4 lo = p[0], hi = p[1];
             Fr v;
-#pragma unroll
-            for (int i = 0; i < 8; i++) v.l[i] = 0;
-            if (idx < msg_len) {
-                if (live) {
-                    uint4 lo = mine[2 * idx], hi = mine[2 * idx + 1];
-                    v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w;
-                    v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
-                }
-            } else if (idx == msg_len && pad_mode == 1) {
-                v = one_mont;
-            }
+            v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w;
+            v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
+            if (pad_mode == 1 && 4 * t + k == len) v = one_mont;      // staged value is zero there
             st[1 + k] = fr_add(st[1 + k], v);
         }
+        __syncthreads();
         Fr out[5];
         fast_perm<5>(&d_fast, st, out, 0);
 #pragma unroll
         for (int w = 0; w < 5; w++) st[w] = out[w];
+        if (t + 1 == blocks) dig = st[1];
     }
-    Fr dig[1] = {st[1]};
-    wave_store_records<1>(digests, rec0, n_msgs, slab, dig);
+    slab_put<1>(slab, 0, dig);
+    slab_flush<1>(digests, rec0, n_msgs, slab);
 }
 
 __device__ __forceinline__ uint64_t splitmix_limb(uint64_t seed, uint64_t idx) {
@@ -338,6 +446,7 @@ const char *hades252_strerror(int code) {
         case HADES252_ERR_NOT_CANONICAL: return "input scalar is not canonical (>= p)";
         case HADES252_ERR_NO_DEVICE: return "no HIP device available";
         case HADES252_ERR_SCRATCH: return "scratch buffer too small";
+        case HADES252_ERR_OUT_OF_CONSTANTS: return "Hades252 out of ARK constants";
         default: return "unknown error";
     }
 }
@@ -565,33 +674,82 @@ int hades252_perm_batch_multi(uint64_t *states, size_t n_perms, int n_devices) {
     return HADES252_OK;
 }
 
-int hades252_perm_trace_dev(const void *d_states, void *d_trace, size_t n_perms, void *stream) {
+int hades252_perm_trace_dev_ex(const void *d_states, void *d_trace, size_t n_perms, void *stream, int kernel) {
     if (n_perms == 0) return HADES252_OK;
     if (d_states == nullptr || d_trace == nullptr || n_perms > kMaxLaunchRecords || misaligned(d_states) ||
         misaligned(d_trace))
         return HADES252_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_perm_trace_literal, dim3(blocks_for(n_perms)), dim3(kBlock), lds_for(5), (hipStream_t)stream,
-                       (const uint8_t *)d_states, (uint8_t *)d_trace, n_perms);
+    if (kernel == HADES252_KERNEL_DEFAULT) kernel = HADES252_KERNEL_FAST;
+    if (kernel == HADES252_KERNEL_LITERAL)
+        hipLaunchKernelGGL(k_perm_trace_literal, dim3(blocks_for(n_perms)), dim3(kBlock), lds_for(5),
+                           (hipStream_t)stream, (const uint8_t *)d_states, (uint8_t *)d_trace, n_perms);
+    else if (kernel == HADES252_KERNEL_FAST)
+        hipLaunchKernelGGL(k_perm_trace_fast, dim3(blocks_for(n_perms)), dim3(kBlock), lds_for(5),
+                           (hipStream_t)stream, (const uint8_t *)d_states, (uint8_t *)d_trace, n_perms);
+    else
+        return HADES252_ERR_INVALID_ARG;
     HIP_TRY(hipGetLastError());
     return HADES252_OK;
 }
 
+int hades252_perm_trace_dev(const void *d_states, void *d_trace, size_t n_perms, void *stream) {
+    return hades252_perm_trace_dev_ex(d_states, d_trace, n_perms, stream, HADES252_KERNEL_DEFAULT);
+}
+
 // ---- per-op --------------------------------------------------------------------------------
-#define STATES_OP(NAME, OPV, NEEDS_ROUND)                                                              \
-    int NAME(void *d_states, size_t n_states, int round, void *stream) {                               \
-        if (n_states == 0) return HADES252_OK;                                                         \
-        if (d_states == nullptr || n_states > kMaxLaunchRecords || misaligned(d_states))               \
-            return HADES252_ERR_INVALID_ARG;                                                           \
-        if (NEEDS_ROUND && (round < 0 || round >= hades252_rounds())) return HADES252_ERR_INVALID_ARG; \
-        hipLaunchKernelGGL(k_states_literal<OPV>, dim3(blocks_for(n_states)), dim3(kBlock), lds_for(5), \
-                           (hipStream_t)stream, (uint8_t *)d_states, n_states, round);                 \
-        HIP_TRY(hipGetLastError());                                                                    \
-        return HADES252_OK;                                                                            \
+// `cursor` = position of the constants iterator the trait methods take (src/strategies.rs:33-41);
+// the reference panics with "Hades252 out of ARK constants" when it runs dry (:40).
+static int states_op_at(int op, void *d_states, size_t n_states, long cursor, void *stream) {
+    if (cursor < 0) return HADES252_ERR_INVALID_ARG;
+    if (cursor + HADES252_WIDTH > HADES_N_ARK) return HADES252_ERR_OUT_OF_CONSTANTS;
+    if (n_states == 0) return HADES252_OK;
+    if (d_states == nullptr || n_states > kMaxLaunchRecords || misaligned(d_states)) return HADES252_ERR_INVALID_ARG;
+    const dim3 grid(blocks_for(n_states)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t *p = (uint8_t *)d_states;
+    switch (op) {
+        case OP_ARK: hipLaunchKernelGGL(k_states_literal<OP_ARK>, grid, block, lds_for(5), s, p, n_states, (int)cursor); break;
+        case OP_FULL: hipLaunchKernelGGL(k_states_literal<OP_FULL>, grid, block, lds_for(5), s, p, n_states, (int)cursor); break;
+        default: hipLaunchKernelGGL(k_states_literal<OP_PARTIAL>, grid, block, lds_for(5), s, p, n_states, (int)cursor); break;
     }
-STATES_OP(hades252_add_round_key_dev, OP_ARK, true)
-STATES_OP(hades252_apply_full_round_dev, OP_FULL, true)
-STATES_OP(hades252_apply_partial_round_dev, OP_PARTIAL, true)
-#undef STATES_OP
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+int hades252_add_round_key_at_dev(void *d_states, size_t n_states, int cursor, void *stream) {
+    return states_op_at(OP_ARK, d_states, n_states, cursor, stream);
+}
+int hades252_apply_full_round_at_dev(void *d_states, size_t n_states, int cursor, void *stream) {
+    return states_op_at(OP_FULL, d_states, n_states, cursor, stream);
+}
+int hades252_apply_partial_round_at_dev(void *d_states, size_t n_states, int cursor, void *stream) {
+    return states_op_at(OP_PARTIAL, d_states, n_states, cursor, stream);
+}
+int hades252_add_round_key_dev(void *d_states, size_t n_states, int round, void *stream) {
+    return states_op_at(OP_ARK, d_states, n_states, 5L * round, stream);
+}
+int hades252_apply_full_round_dev(void *d_states, size_t n_states, int round, void *stream) {
+    return states_op_at(OP_FULL, d_states, n_states, 5L * round, stream);
+}
+int hades252_apply_partial_round_dev(void *d_states, size_t n_states, int round, void *stream) {
+    return states_op_at(OP_PARTIAL, d_states, n_states, 5L * round, stream);
+}
+
+int hades252_fr_op_dev(int op, int impl, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream) {
+    if (op < FR_ADD || op > FR_FROM_RAW || (impl != 0 && impl != 1)) return HADES252_ERR_INVALID_ARG;
+    if (n == 0) return HADES252_OK;
+    const bool binary = (op == FR_ADD || op == FR_MUL);
+    if (d_a == nullptr || d_out == nullptr || (binary && d_b == nullptr) || n > kMaxLaunchRecords || misaligned(d_a) ||
+        misaligned(d_out) || (binary && misaligned(d_b)))
+        return HADES252_ERR_INVALID_ARG;
+    if (impl == 0)
+        hipLaunchKernelGGL(k_fr_op<0>, dim3(blocks_for(n)), dim3(kBlock), lds_for(1), (hipStream_t)stream,
+                           (const uint8_t *)d_a, (const uint8_t *)d_b, (uint8_t *)d_out, n, op);
+    else
+        hipLaunchKernelGGL(k_fr_op<1>, dim3(blocks_for(n)), dim3(kBlock), lds_for(1), (hipStream_t)stream,
+                           (const uint8_t *)d_a, (const uint8_t *)d_b, (uint8_t *)d_out, n, op);
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
 
 int hades252_mul_matrix_dev(void *d_states, size_t n_states, void *stream) {
     if (n_states == 0) return HADES252_OK;
@@ -653,21 +811,37 @@ int hades252_merkle4_level_dev(const void *d_children, void *d_parents, size_t n
     return HADES252_OK;
 }
 
+static int sponge_launch(const void *d_scalars, const uint64_t *d_offsets, const uint64_t *d_lengths, size_t n_msgs,
+                         size_t fixed_len, const uint64_t capacity_mont[4], int pad_mode, void *d_digests, void *stream) {
+    Fr cap;
+    for (int k = 0; k < 4; k++) {
+        cap.l[2 * k] = (uint32_t)capacity_mont[k];
+        cap.l[2 * k + 1] = (uint32_t)(capacity_mont[k] >> 32);
+    }
+    hipLaunchKernelGGL(k_sponge, dim3(blocks_for(n_msgs)), dim3(kBlock), lds_for(4), (hipStream_t)stream,
+                       (const uint8_t *)d_scalars, d_offsets, d_lengths, (uint8_t *)d_digests, n_msgs, fixed_len, cap,
+                       pad_mode);
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
 int hades252_sponge_hash_dev(const void *d_msgs, size_t n_msgs, size_t msg_len, const uint64_t capacity_mont[4],
                              int pad_mode, void *d_digests, void *stream) {
     if (n_msgs == 0) return HADES252_OK;
     if (d_digests == nullptr || capacity_mont == nullptr || (d_msgs == nullptr && msg_len > 0) ||
         (pad_mode != 0 && pad_mode != 1) || n_msgs > kMaxLaunchRecords || misaligned(d_msgs) || misaligned(d_digests))
         return HADES252_ERR_INVALID_ARG;
-    Fr cap;
-    for (int k = 0; k < 4; k++) {
-        cap.l[2 * k] = (uint32_t)capacity_mont[k];
-        cap.l[2 * k + 1] = (uint32_t)(capacity_mont[k] >> 32);
-    }
-    hipLaunchKernelGGL(k_sponge_fixed, dim3(blocks_for(n_msgs)), dim3(kBlock), lds_for(1), (hipStream_t)stream,
-                       (const uint8_t *)d_msgs, (uint8_t *)d_digests, n_msgs, msg_len, cap, pad_mode);
-    HIP_TRY(hipGetLastError());
-    return HADES252_OK;
+    return sponge_launch(d_msgs, nullptr, nullptr, n_msgs, msg_len, capacity_mont, pad_mode, d_digests, stream);
+}
+
+int hades252_sponge_hash_var_dev(const void *d_scalars, const uint64_t *d_offsets, const uint64_t *d_lengths,
+                                 size_t n_msgs, const uint64_t capacity_mont[4], int pad_mode, void *d_digests,
+                                 void *stream) {
+    if (n_msgs == 0) return HADES252_OK;
+    if (d_digests == nullptr || capacity_mont == nullptr || d_offsets == nullptr || d_lengths == nullptr ||
+        (pad_mode != 0 && pad_mode != 1) || n_msgs > kMaxLaunchRecords || misaligned(d_scalars) || misaligned(d_digests))
+        return HADES252_ERR_INVALID_ARG;
+    return sponge_launch(d_scalars, d_offsets, d_lengths, n_msgs, 0, capacity_mont, pad_mode, d_digests, stream);
 }
 
 static bool is_pow4(size_t n) { return n >= 4 && (n & (n - 1)) == 0 && (__builtin_ctzll(n) % 2) == 0; }

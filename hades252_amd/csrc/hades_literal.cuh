@@ -20,7 +20,7 @@ namespace hades {
 // emits scalar loads (s_load_dwordx8 through the scalar data cache) and the constants arrive in
 // SGPRs -- a wave-wide broadcast that costs no VGPRs, no LDS bandwidth and no VALU issue.
 struct LiteralView {
-    const uint32_t (*ark)[8];   // ROUND_CONSTANTS[0..335), Montgomery form
+    const uint32_t (*ark)[8];   // ROUND_CONSTANTS[0..960), Montgomery form
     const uint32_t (*mds)[8];   // MDS_MATRIX row-major, Montgomery form
 };
 
@@ -31,9 +31,10 @@ __device__ __forceinline__ Fr load_const(const uint32_t (*tab)[8], int idx) {
     return c;
 }
 
-__device__ __forceinline__ void lit_add_round_key(const LiteralView &T, int round, Fr (&st)[5]) {
+// `cursor` = position of the constants iterator (src/strategies.rs:33-41); perm() uses 5 * round
+__device__ __forceinline__ void lit_add_round_key(const LiteralView &T, int cursor, Fr (&st)[5]) {
 #pragma unroll
-    for (int w = 0; w < 5; w++) st[w] = fr_add(st[w], load_const(T.ark, 5 * round + w));
+    for (int w = 0; w < 5; w++) st[w] = fr_add(st[w], load_const(T.ark, cursor + w));
 }
 
 __device__ __forceinline__ Fr lit_quintic_s_box(const Fr &v) {
@@ -54,27 +55,27 @@ __device__ __forceinline__ void lit_mul_matrix(const LiteralView &T, Fr (&st)[5]
     for (int k = 0; k < 5; k++) st[k] = res[k];
 }
 
-__device__ __forceinline__ void lit_full_round(const LiteralView &T, int round, Fr (&st)[5]) {
-    lit_add_round_key(T, round, st);
+__device__ __forceinline__ void lit_full_round(const LiteralView &T, int cursor, Fr (&st)[5]) {
+    lit_add_round_key(T, cursor, st);
 #pragma unroll
     for (int w = 0; w < 5; w++) st[w] = lit_quintic_s_box(st[w]);
     lit_mul_matrix(T, st);
 }
 
-__device__ __forceinline__ void lit_partial_round(const LiteralView &T, int round, Fr (&st)[5]) {
-    lit_add_round_key(T, round, st);
+__device__ __forceinline__ void lit_partial_round(const LiteralView &T, int cursor, Fr (&st)[5]) {
+    lit_add_round_key(T, cursor, st);
     st[4] = lit_quintic_s_box(st[4]);
     lit_mul_matrix(T, st);
 }
 
 __device__ __forceinline__ void lit_perm(const LiteralView &T, Fr (&st)[5]) {
-    int round = 0;
+    int cursor = 0;
 #pragma unroll 1
-    for (int i = 0; i < 4; i++, round++) lit_full_round(T, round, st);
+    for (int i = 0; i < 4; i++, cursor += 5) lit_full_round(T, cursor, st);
 #pragma unroll 1
-    for (int i = 0; i < 59; i++, round++) lit_partial_round(T, round, st);
+    for (int i = 0; i < 59; i++, cursor += 5) lit_partial_round(T, cursor, st);
 #pragma unroll 1
-    for (int i = 0; i < 4; i++, round++) lit_full_round(T, round, st);
+    for (int i = 0; i < 4; i++, cursor += 5) lit_full_round(T, cursor, st);
 }
 
 }  // namespace hades

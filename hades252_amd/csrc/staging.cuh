@@ -22,7 +22,7 @@ __host__ __device__ constexpr int lds_wave_bytes(int nw) { return kWave * lds_re
 // Load the records [rec0, rec0+64) (clipped to n_recs) of `base` into per-lane state.
 // `slab` is this wave's LDS slab (lds_wave_bytes(NW)).  Lanes past the end get zeros.
 template <int NW>
-__device__ __forceinline__ void wave_load_records(const uint8_t *__restrict__ base, size_t rec0, size_t n_recs,
+__device__ __forceinline__ void wave_load_records(const uint8_t *base, size_t rec0, size_t n_recs,
                                                   uint8_t *slab, Fr (&st)[NW]) {
     constexpr int kLdsRecBytes = lds_rec_bytes(NW);
     const int lane = threadIdx.x & (kWave - 1);
@@ -49,9 +49,42 @@ __device__ __forceinline__ void wave_load_records(const uint8_t *__restrict__ ba
     __syncthreads();
 }
 
-// Store per-lane state to records [rec0, rec0+64) (clipped to n_recs).
+// Word w of this lane's record -> the wave's slab (no synchronisation; see slab_flush).
 template <int NW>
-__device__ __forceinline__ void wave_store_records(uint8_t *__restrict__ base, size_t rec0, size_t n_recs,
+__device__ __forceinline__ void slab_put(uint8_t *slab, int w, const Fr &v) {
+    constexpr int kLdsRecBytes = lds_rec_bytes(NW);
+    const int lane = threadIdx.x & (kWave - 1);
+    uint4 *p = reinterpret_cast<uint4 *>(slab + lane * kLdsRecBytes + w * 32);
+    p[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    p[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// Slab (filled with slab_put by every lane) -> records [rec0, rec0+64) (clipped to n_recs).
+// Block-wide barriers: every wave of the block must call it the same number of times.
+template <int NW>
+__device__ __forceinline__ void slab_flush(uint8_t *base, size_t rec0, size_t n_recs, uint8_t *slab) {
+    constexpr int kLdsRecBytes = lds_rec_bytes(NW);
+    const int lane = threadIdx.x & (kWave - 1);
+    __syncthreads();
+    const size_t rec_bytes = (size_t)NW * 32;
+    const size_t total_chunks = n_recs * (size_t)(2 * NW);
+    uint4 *g = reinterpret_cast<uint4 *>(base + rec0 * rec_bytes);
+    const size_t chunk0 = rec0 * (size_t)(2 * NW);
+#pragma unroll
+    for (int k = 0; k < 2 * NW; k++) {
+        int c = k * kWave + lane;
+        int rec = c / (2 * NW), part = c - rec * (2 * NW);
+        uint4 v = *reinterpret_cast<const uint4 *>(slab + rec * kLdsRecBytes + part * 16);
+        if (chunk0 + c < total_chunks) g[c] = v;
+    }
+    __syncthreads();
+}
+
+// Store per-lane state to records [rec0, rec0+64) (clipped to n_recs).
+// `base` may alias the buffer the records were loaded from (in-place kernels): a wave has loaded all
+// of its records before it stores any, and waves own disjoint record ranges -- hence no __restrict__.
+template <int NW>
+__device__ __forceinline__ void wave_store_records(uint8_t *base, size_t rec0, size_t n_recs,
                                                    uint8_t *slab, const Fr (&st)[NW]) {
     constexpr int kLdsRecBytes = lds_rec_bytes(NW);
     const int lane = threadIdx.x & (kWave - 1);

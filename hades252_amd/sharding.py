@@ -80,6 +80,29 @@ def reduce_sum_int(value: int, device="cpu") -> int:
     return int(t.item())
 
 
+def reduce_min_int(value: int, device="cpu") -> int:
+    """MIN over ranks (used as a logical AND of per-rank verification results)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return value
+    t = torch.tensor([value], dtype=torch.int64, device=_comm_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
+def gather_floats(value: float, device="cpu") -> List[float]:
+    """Every rank's value, in rank order (bookkeeping only: per-GPU kernel times)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [value]
+    t = torch.tensor([value], dtype=torch.float64, device=_comm_device(device))
+    outs = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [float(o.item()) for o in outs]
+
+
 def combine_digests(digest4: List[int], device="cpu") -> List[int]:
     """Digests are additive over disjoint index ranges (include/hades252.h): the digest of the
     whole job is the limb-wise wrapping sum of the shard digests.  Sent as 8 x 32-bit halves so

@@ -128,22 +128,20 @@ class ScalarStrategy(Strategy):
         return cls()
 
     @staticmethod
-    def _round_of(constants: RoundConstantsIter, what: str) -> int:
-        if constants.pos % WIDTH != 0:
-            raise ValueError("%s: constant cursor %d is not at a round boundary" % (what, constants.pos))
-        rnd = constants.pos // WIDTH
-        if rnd >= Strategy.rounds():
-            # the device table holds the 335 constants `perm` consumes
+    def _cursor_of(constants: RoundConstantsIter) -> int:
+        # any cursor is legal (the trait methods take the iterator wherever it stands,
+        # src/strategies.rs:33-41); running past the 960 constants is the reference's panic
+        if constants.pos + WIDTH > N_ROUND_CONSTANTS:
             raise RuntimeError("Hades252 out of ARK constants")
-        return rnd
+        return constants.pos
 
     def add_round_key(self, constants: RoundConstantsIter, words) -> None:
         """src/strategies/scalar.rs:23-30: word w of every state += next_c()."""
         import torch
         ptr, n, dev = _dev_buffer(words, STATE_BYTES, "add_round_key")
-        rnd = self._round_of(constants, "add_round_key")
+        cur = self._cursor_of(constants)
         with torch.cuda.device(dev):
-            check(_lib.lib().hades252_add_round_key_dev(ptr, n, rnd, _stream_ptr(dev)), "add_round_key")
+            check(_lib.lib().hades252_add_round_key_at_dev(ptr, n, cur, _stream_ptr(dev)), "add_round_key")
         for _ in range(WIDTH):
             self.next_c(constants)
 
@@ -165,9 +163,9 @@ class ScalarStrategy(Strategy):
         """src/strategies.rs:79-93, fused in one launch."""
         import torch
         ptr, n, dev = _dev_buffer(words, STATE_BYTES, "apply_partial_round")
-        rnd = self._round_of(constants, "apply_partial_round")
+        cur = self._cursor_of(constants)
         with torch.cuda.device(dev):
-            check(_lib.lib().hades252_apply_partial_round_dev(ptr, n, rnd, _stream_ptr(dev)), "apply_partial_round")
+            check(_lib.lib().hades252_apply_partial_round_at_dev(ptr, n, cur, _stream_ptr(dev)), "apply_partial_round")
         for _ in range(WIDTH):
             self.next_c(constants)
 
@@ -175,9 +173,9 @@ class ScalarStrategy(Strategy):
         """src/strategies.rs:107-119, fused in one launch."""
         import torch
         ptr, n, dev = _dev_buffer(words, STATE_BYTES, "apply_full_round")
-        rnd = self._round_of(constants, "apply_full_round")
+        cur = self._cursor_of(constants)
         with torch.cuda.device(dev):
-            check(_lib.lib().hades252_apply_full_round_dev(ptr, n, rnd, _stream_ptr(dev)), "apply_full_round")
+            check(_lib.lib().hades252_apply_full_round_at_dev(ptr, n, cur, _stream_ptr(dev)), "apply_full_round")
         for _ in range(WIDTH):
             self.next_c(constants)
 
@@ -208,16 +206,35 @@ class ScalarStrategy(Strategy):
             self.apply_full_round(constants, data)
 
 
-def perm_trace(states_t):
+def perm_trace(states_t, kernel: int = _lib.KERNEL_DEFAULT, out=None):
     """State after every round (round-major: result[r] is the batch after round r); the input is
     left untouched.  Witness pre-computation for the reference's GadgetStrategy
     (src/strategies/gadget.rs:41-133)."""
     import torch
     ptr, n, dev = _dev_buffer(states_t, STATE_BYTES, "perm_trace")
-    trace = torch.empty((Strategy.rounds(), n, WIDTH, 4), dtype=torch.int64, device=dev)
+    trace = torch.empty((Strategy.rounds(), n, WIDTH, 4), dtype=torch.int64, device=dev) if out is None else out
     with torch.cuda.device(dev):
-        check(_lib.lib().hades252_perm_trace_dev(ptr, trace.data_ptr(), n, _stream_ptr(dev)), "perm_trace")
+        check(_lib.lib().hades252_perm_trace_dev_ex(ptr, trace.data_ptr(), n, _stream_ptr(dev), kernel), "perm_trace")
     return trace
+
+
+FR_ADD, FR_MUL, FR_SQUARE, FR_FROM_RAW = 0, 1, 2, 3
+FR_IMPL_SATURATED32, FR_IMPL_RADIX29 = 0, 1
+
+
+def fr_op(op: int, a_t, b_t=None, impl: int = FR_IMPL_RADIX29):
+    """Batched ``BlsScalar`` add / mul / square / from_raw on device (include/hades252.h)."""
+    import torch
+    ptr, n, dev = _dev_buffer(a_t, 32, "fr_op")
+    bptr = 0
+    if b_t is not None:
+        bptr, nb, _ = _dev_buffer(b_t, 32, "fr_op")
+        if nb != n:
+            raise ValueError("fr_op: operand sizes differ")
+    out = torch.empty_like(a_t)
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_fr_op_dev(op, impl, ptr, bptr, out.data_ptr(), n, _stream_ptr(dev)), "fr_op")
+    return out
 
 
 # ---- helpers around the strategy (wire format, Merkle, synthetic data) ----------------------
@@ -297,6 +314,22 @@ def sponge_hash(msgs_t, msg_len: int, capacity_mont: int, pad_mode: int = 1):
     with torch.cuda.device(dev):
         check(_lib.lib().hades252_sponge_hash_dev(ptr, n, msg_len, _tag_arr(capacity_mont), pad_mode,
                                                   out.data_ptr(), _stream_ptr(dev)), "sponge_hash")
+    return out
+
+
+def sponge_hash_var(scalars_t, offsets_t, lengths_t, capacity_mont: int, pad_mode: int = 1):
+    """Batched variable-length sponge: message i = scalars[offsets[i] : offsets[i] + lengths[i]]
+    (offsets / lengths: int64 CUDA tensors, in scalars).  Returns [n, 4] int64 digests."""
+    import torch
+    sptr, n_scalars, dev = _dev_buffer(scalars_t, 32, "sponge_hash_var")
+    optr, n, _ = _dev_buffer(offsets_t, 8, "sponge_hash_var")
+    lptr, n2, _ = _dev_buffer(lengths_t, 8, "sponge_hash_var")
+    if n != n2:
+        raise ValueError("sponge_hash_var: offsets and lengths differ in size")
+    out = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_sponge_hash_var_dev(sptr, optr, lptr, n, _tag_arr(capacity_mont), pad_mode,
+                                                      out.data_ptr(), _stream_ptr(dev)), "sponge_hash_var")
     return out
 
 

@@ -52,6 +52,8 @@ extern "C" {
 #define HADES252_ERR_NOT_CANONICAL (-3) /* a canonical-bytes input encodes a value >= p */
 #define HADES252_ERR_NO_DEVICE (-4)     /* no HIP device visible */
 #define HADES252_ERR_SCRATCH (-5)       /* scratch buffer too small */
+#define HADES252_ERR_OUT_OF_CONSTANTS (-6) /* cursor + WIDTH > 960: the reference panics with
+                                              "Hades252 out of ARK constants" (src/strategies.rs:40) */
 
 /* kernel selectors for hades252_perm_batch_dev_ex (both produce identical bits) */
 #define HADES252_KERNEL_DEFAULT 0
@@ -85,10 +87,17 @@ int hades252_perm_batch_multi(uint64_t *states, size_t n_perms, int n_devices);
  * state of every permutation after round r's mul_matrix; trace[66] equals the perm output.
  * d_states is not modified.  Needs 67 * 160 * n_perms bytes. */
 int hades252_perm_trace_dev(const void *d_states, void *d_trace, size_t n_perms, void *stream);
+/* kernel: HADES252_KERNEL_FAST (default; the rounds of the shipped kernel, each state un-scaled with one
+ * constant product per word) or HADES252_KERNEL_LITERAL (the reference's schedule); identical bits. */
+int hades252_perm_trace_dev_ex(const void *d_states, void *d_trace, size_t n_perms, void *stream, int kernel);
 
 /* ---- the trait's per-operation methods, batched on device ------------------------------- */
-/* Strategy::add_round_key (src/strategies/scalar.rs:23-30) with the cursor at 5*round:
- * word w of every state += ROUND_CONSTANTS[5*round + w].  0 <= round < 67. */
+/* Strategy::add_round_key (src/strategies/scalar.rs:23-30).  The trait method takes the constants
+ * ITERATOR (src/strategies.rs:33-41, :50-52); `cursor` is its position: word w of every state +=
+ * ROUND_CONSTANTS[cursor + w].  Any 0 <= cursor <= 955 of the 960 constants (src/round_constants.rs:18)
+ * is accepted; beyond that the reference panics "Hades252 out of ARK constants" and this returns
+ * HADES252_ERR_OUT_OF_CONSTANTS.  The `round` forms are cursor = 5*round (what perm() does). */
+int hades252_add_round_key_at_dev(void *d_states, size_t n_states, int cursor, void *stream);
 int hades252_add_round_key_dev(void *d_states, size_t n_states, int round, void *stream);
 /* Strategy::quintic_s_box (src/strategies/scalar.rs:32-34) on n_scalars independent scalars. */
 int hades252_quintic_s_box_dev(void *d_scalars, size_t n_scalars, void *stream);
@@ -97,6 +106,21 @@ int hades252_mul_matrix_dev(void *d_states, size_t n_states, void *stream);
 /* Strategy::apply_full_round / apply_partial_round (src/strategies.rs:107-119, :79-93). */
 int hades252_apply_full_round_dev(void *d_states, size_t n_states, int round, void *stream);
 int hades252_apply_partial_round_dev(void *d_states, size_t n_states, int round, void *stream);
+int hades252_apply_full_round_at_dev(void *d_states, size_t n_states, int cursor, void *stream);
+int hades252_apply_partial_round_at_dev(void *d_states, size_t n_states, int cursor, void *stream);
+
+/* ---- BlsScalar arithmetic, batched (external crate dusk-bls12_381; call sites src/strategies/scalar.rs:28,
+ * :33, :44, src/round_constants.rs:41) ------------------------------------------------------------------
+ * out[i] = a[i] op b[i] on Montgomery limbs (32 B each, fully reduced in and out; out may alias a or b).
+ * op: 0 add, 1 mul, 2 square (b ignored), 3 from_raw (a = canonical limbs, b ignored).
+ * impl: 0 = saturated 8 x u32 arithmetic of the literal kernels, 1 = radix-2^29 signed-limb arithmetic
+ * of the shipped kernel.  Both give identical bits; tests regenerate the reference's constant blobs
+ * through each of them. */
+#define HADES252_FR_ADD 0
+#define HADES252_FR_MUL 1
+#define HADES252_FR_SQUARE 2
+#define HADES252_FR_FROM_RAW 3
+int hades252_fr_op_dev(int op, int impl, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
 
 /* ---- wire format on device: BlsScalar::from_bytes / to_bytes ------------------------------ */
 /* d_bad_count (device int, may be NULL) is incremented once per input >= p; such inputs
@@ -115,7 +139,7 @@ size_t hades252_merkle4_scratch_bytes(size_t n_leaves);
 int hades252_merkle4_root_dev(const void *d_leaves, size_t n_leaves, void *d_scratch, size_t scratch_bytes,
                               const uint64_t tag_mont[4], int out_idx, void *d_root, void *stream);
 
-/* ---- batched fixed-length sponge (caller shape of dusk-poseidon's sponge hash, README.md:9) ----
+/* ---- batched sponge (caller shape of dusk-poseidon's sponge hash, README.md:9) ----
  * d_msgs: n_msgs messages of msg_len scalars each (Montgomery limbs, contiguous: message i at scalar
  * offset i*msg_len).  state = [capacity, 0, 0, 0, 0]; each block of 4 scalars is added to words 1..4,
  * then permuted; pad_mode 1 first appends a single scalar 1 (then zeros), pad_mode 0 zero-fills;
@@ -124,6 +148,12 @@ int hades252_merkle4_root_dev(const void *d_leaves, size_t n_leaves, void *d_scr
  * entry point's parity is pinned to this repo's oracle only. */
 int hades252_sponge_hash_dev(const void *d_msgs, size_t n_msgs, size_t msg_len, const uint64_t capacity_mont[4],
                              int pad_mode, void *d_digests, void *stream);
+/* Variable-length batch: message i = d_scalars[d_offsets[i] .. d_offsets[i] + d_lengths[i]) (offsets and
+ * lengths in scalars, device arrays of n_msgs u64; messages may overlap or leave gaps; length 0 allowed).
+ * Same absorption / padding rule per message as above (CONVENTION UNPINNED: parameters, see above). */
+int hades252_sponge_hash_var_dev(const void *d_scalars, const uint64_t *d_offsets, const uint64_t *d_lengths,
+                                 size_t n_msgs, const uint64_t capacity_mont[4], int pad_mode, void *d_digests,
+                                 void *stream);
 
 /* ---- synthetic inputs and digests (benchmark / verification plumbing) --------------------- */
 /* Generator B: scalar e (global element index first_elem + k) gets 4 splitmix64 limbs, top limb

@@ -75,10 +75,10 @@ public:
 
 // GPU-backed ScalarStrategy.  Stateless like the reference's zero-sized struct.
 class ScalarStrategy : public Strategy<DeviceStates> {
-    static int round_of(RoundConstantsIter &c, const char *where) {
-        if (c.pos % WIDTH != 0) throw HadesPanic(std::string(where) + ": cursor not at a round boundary", -1);
-        if (c.pos / WIDTH >= rounds()) throw HadesPanic("Hades252 out of ARK constants", -1);
-        return static_cast<int>(c.pos / WIDTH);
+    // any cursor is legal (src/strategies.rs:33-41); past the 960 constants the reference panics
+    static int cursor_of(RoundConstantsIter &c) {
+        if (c.pos + WIDTH > RoundConstantsIter::CONSTANTS) throw HadesPanic("Hades252 out of ARK constants", -6);
+        return static_cast<int>(c.pos);
     }
     static void advance(RoundConstantsIter &c) {
         for (std::size_t i = 0; i < WIDTH; i++) next_c(c);
@@ -88,7 +88,7 @@ public:
     static ScalarStrategy new_() { return ScalarStrategy(); }   // src/strategies/scalar.rs:17-19
 
     void add_round_key(RoundConstantsIter &constants, DeviceStates w) override {   // scalar.rs:23-30
-        check(hades252_add_round_key_dev(w.ptr, w.n_states, round_of(constants, "add_round_key"), w.stream),
+        check(hades252_add_round_key_at_dev(w.ptr, w.n_states, cursor_of(constants), w.stream),
               "add_round_key");
         advance(constants);
     }
@@ -100,12 +100,12 @@ public:
         check(hades252_mul_matrix_dev(v.ptr, v.n_states, v.stream), "mul_matrix");
     }
     void apply_partial_round(RoundConstantsIter &constants, DeviceStates w) override {
-        check(hades252_apply_partial_round_dev(w.ptr, w.n_states, round_of(constants, "apply_partial_round"), w.stream),
+        check(hades252_apply_partial_round_at_dev(w.ptr, w.n_states, cursor_of(constants), w.stream),
               "apply_partial_round");
         advance(constants);
     }
     void apply_full_round(RoundConstantsIter &constants, DeviceStates w) override {
-        check(hades252_apply_full_round_dev(w.ptr, w.n_states, round_of(constants, "apply_full_round"), w.stream),
+        check(hades252_apply_full_round_at_dev(w.ptr, w.n_states, cursor_of(constants), w.stream),
               "apply_full_round");
         advance(constants);
     }

@@ -234,12 +234,16 @@ void hades_oracle_perm_trace(uint64_t *state, uint64_t *trace) {
 void hades_oracle_perm(uint64_t *state) { hades_oracle_perm_trace(state, NULL); }
 
 /* ---- per-operation entry points (batched, for the per-op kernels' parity tests) ------ */
-void hades_oracle_add_round_key(uint64_t *states, size_t n, int round) {
+/* add_round_key with the constants iterator standing at `cursor` (src/strategies.rs:33-41) */
+void hades_oracle_add_round_key_at(uint64_t *states, size_t n, int cursor_pos) {
     hades_oracle_init();
     for (size_t i = 0; i < n; i++) {
-        const fr_t *cursor = ROUND_CONSTANTS + WIDTH * round;
+        const fr_t *cursor = ROUND_CONSTANTS + cursor_pos;
         add_round_key(&cursor, (fr_t *)(states + 20 * i));
     }
+}
+void hades_oracle_add_round_key(uint64_t *states, size_t n, int round) {
+    hades_oracle_add_round_key_at(states, n, WIDTH * round);
 }
 void hades_oracle_quintic_s_box(uint64_t *scalars, size_t n) {
     for (size_t i = 0; i < n; i++) {
@@ -351,34 +355,43 @@ void hades_oracle_merkle4_level(const uint64_t *children, uint64_t *parents, siz
     for (int t = 1; t < n_threads; t++) pthread_join(th[t], NULL);
 }
 
-/* ---- fixed-length sponge: state = [cap,0,0,0,0]; add 4 scalars to words 1..4, perm; pad_mode 1
- * appends a single 1 first; at least one perm.  Digest = word 1.  (Caller shape of
- * dusk-poseidon, which is not part of the reference tree: convention = parameters.) ---------- */
-void hades_oracle_sponge(const uint64_t *msgs, size_t n_msgs, size_t msg_len, const uint64_t *cap_mont,
-                         int pad_mode, uint64_t *digests) {
-    hades_oracle_init();
+/* ---- sponge: state = [cap,0,0,0,0]; add 4 scalars to words 1..4, perm; pad_mode 1 appends a single 1
+ * first; at least one perm.  Digest = word 1.  (Caller shape of dusk-poseidon, README.md:9, which is
+ * not part of the reference tree: the convention is a set of PARAMETERS, unpinned.) ---------------- */
+static void sponge_one(const uint64_t *msg, size_t msg_len, const uint64_t *cap_mont, int pad_mode, uint64_t *digest) {
     const uint64_t one_raw[4] = {1, 0, 0, 0};
     const fr_t one = fr_from_raw(one_raw);
     size_t padded = msg_len + (pad_mode == 1 ? 1 : 0);
     size_t blocks = (padded + 3) / 4;
     if (blocks == 0) blocks = 1;
-    for (size_t i = 0; i < n_msgs; i++) {
-        fr_t st[WIDTH];
-        memset(st, 0, sizeof st);
-        memcpy(st[0].l, cap_mont, 32);
-        for (size_t t = 0; t < blocks; t++) {
-            for (int k = 0; k < 4; k++) {
-                size_t idx = 4 * t + k;
-                fr_t v;
-                memset(&v, 0, sizeof v);
-                if (idx < msg_len) memcpy(v.l, msgs + 4 * (i * msg_len + idx), 32);
-                else if (idx == msg_len && pad_mode == 1) v = one;
-                st[1 + k] = fr_add(st[1 + k], v);
-            }
-            hades_oracle_perm((uint64_t *)st);
+    fr_t st[WIDTH];
+    memset(st, 0, sizeof st);
+    memcpy(st[0].l, cap_mont, 32);
+    for (size_t t = 0; t < blocks; t++) {
+        for (int k = 0; k < 4; k++) {
+            size_t idx = 4 * t + k;
+            fr_t v;
+            memset(&v, 0, sizeof v);
+            if (idx < msg_len) memcpy(v.l, msg + 4 * idx, 32);
+            else if (idx == msg_len && pad_mode == 1) v = one;
+            st[1 + k] = fr_add(st[1 + k], v);
         }
-        memcpy(digests + 4 * i, st[1].l, 32);
+        hades_oracle_perm((uint64_t *)st);
     }
+    memcpy(digest, st[1].l, 32);
+}
+/* fixed length: message i = msgs[i*msg_len .. (i+1)*msg_len) */
+void hades_oracle_sponge(const uint64_t *msgs, size_t n_msgs, size_t msg_len, const uint64_t *cap_mont,
+                         int pad_mode, uint64_t *digests) {
+    hades_oracle_init();
+    for (size_t i = 0; i < n_msgs; i++) sponge_one(msgs + 4 * i * msg_len, msg_len, cap_mont, pad_mode, digests + 4 * i);
+}
+/* variable length: message i = scalars[offsets[i] .. offsets[i] + lengths[i]) */
+void hades_oracle_sponge_var(const uint64_t *scalars, const uint64_t *offsets, const uint64_t *lengths, size_t n_msgs,
+                             const uint64_t *cap_mont, int pad_mode, uint64_t *digests) {
+    hades_oracle_init();
+    for (size_t i = 0; i < n_msgs; i++)
+        sponge_one(scalars + 4 * offsets[i], (size_t)lengths[i], cap_mont, pad_mode, digests + 4 * i);
 }
 
 /* ---- field-op exports for unit tests -------------------------------------------------- */

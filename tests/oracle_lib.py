@@ -63,6 +63,11 @@ class Oracle:
         self.l.hades_oracle_add_round_key(_p(out), ctypes.c_size_t(out.size // 20), ctypes.c_int(rnd))
         return out
 
+    def add_round_key_at(self, states, cursor):
+        out = np.ascontiguousarray(states, dtype=np.uint64).copy()
+        self.l.hades_oracle_add_round_key_at(_p(out), ctypes.c_size_t(out.size // 20), ctypes.c_int(cursor))
+        return out
+
     def quintic_s_box(self, scalars):
         out = np.ascontiguousarray(scalars, dtype=np.uint64).copy()
         self.l.hades_oracle_quintic_s_box(_p(out), ctypes.c_size_t(out.size // 4))
@@ -77,6 +82,14 @@ class Oracle:
         st = self.add_round_key(states, rnd)
         st = self.quintic_s_box(st)
         return self.mul_matrix(st)
+
+    def full_round_at(self, states, cursor):
+        return self.mul_matrix(self.quintic_s_box(self.add_round_key_at(states, cursor)))
+
+    def partial_round_at(self, states, cursor):
+        st = self.add_round_key_at(states, cursor).reshape(-1, 5, 4)
+        st[:, 4, :] = self.quintic_s_box(st[:, 4, :].copy()).reshape(-1, 4)
+        return self.mul_matrix(st.reshape(-1))
 
     def partial_round(self, states, rnd):
         st = self.add_round_key(states, rnd).reshape(-1, 5, 4)
@@ -115,6 +128,16 @@ class Oracle:
         cap = np.array(limbs_of(cap_mont), dtype=np.uint64)
         self.l.hades_oracle_sponge(_p(m), ctypes.c_size_t(n), ctypes.c_size_t(msg_len), _p(cap),
                                    ctypes.c_int(pad_mode), _p(out))
+        return out
+
+    def sponge_var(self, scalars, offsets, lengths, cap_mont, pad_mode=1):
+        m = np.ascontiguousarray(scalars, dtype=np.uint64)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+        out = np.zeros(4 * off.size, dtype=np.uint64)
+        cap = np.array(limbs_of(cap_mont), dtype=np.uint64)
+        self.l.hades_oracle_sponge_var(_p(m), _p(off), _p(ln), ctypes.c_size_t(off.size), _p(cap),
+                                       ctypes.c_int(pad_mode), _p(out))
         return out
 
     def from_bytes(self, b32):

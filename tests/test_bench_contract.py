@@ -41,3 +41,15 @@ def test_bench_single_and_two_ranks_agree():
     assert two["n_gpus"] == 2 and "cpu_baseline" not in two
     # same global batch (2 x per states, same generator indices), same number of passes
     assert two["digest"] == one["digest"]
+    assert two["parity_vs_cpu_sample"] is True and len(two["per_gpu"]["kernel_ms_per_rank"]) == 2
+    # self-launch: `python bench.py --gpus 2` with no torchrun around it spawns its own ranks
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--perms-per-gpu",
+                        str(per), "--dist-backend", "gloo", "--single-device"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=900, env=env_clean)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    self_launched = json.loads(lines[0])
+    assert self_launched["n_gpus"] == 2 and self_launched["digest"] == one["digest"]
+    assert self_launched["parity_vs_cpu_sample"] is True

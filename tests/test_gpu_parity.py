@@ -158,7 +158,7 @@ def test_per_op_kernels(torch_cuda, H, oracle):
     strat.mul_matrix(H.RoundConstantsIter(), buf)
     assert (to_host(buf) == oracle.mul_matrix(inp)).all()
     with pytest.raises(RuntimeError, match="out of ARK constants"):
-        strat.add_round_key(H.RoundConstantsIter(335), buf)
+        strat.add_round_key(H.RoundConstantsIter(956), buf)
 
 
 def test_perm_is_the_composition_of_rounds(torch_cuda, H, oracle):

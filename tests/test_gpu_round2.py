@@ -1,0 +1,298 @@
+"""GPU tier, round 2: blob KATs through the device arithmetic, free constant cursor, fast trace,
+variable-length sponge, and BASELINE config 5 at its real size.  Everything goes through the C ABI."""
+import hashlib
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import hades_spec as S  # noqa: E402
+from oracle_lib import P, R, limbs_of, int_of  # noqa: E402
+from test_blob_kat import ARK_SHA256, MDS_SHA256  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def H(hades_lib):
+    from hades252_amd import strategy
+    return strategy
+
+
+def to_dev(torch, arr):
+    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint64).view(np.int64)).cuda()
+
+
+def to_host(t):
+    return t.cpu().numpy().view(np.uint64).reshape(-1)
+
+
+def scalars_dev(torch, ints):
+    return to_dev(torch, np.array([l for v in ints for l in limbs_of(v)], dtype=np.uint64)).view(-1, 4)
+
+
+# ---------------------------------------------------------------------------------------------
+# Pin #0 on the device: both device arithmetics regenerate the reference's blobs
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("impl", [0, 1])
+def test_mds_blob_through_device_field_ops(torch_cuda, H, impl):
+    """assets/mds.bin (written by the real dusk-bls12_381, HOWTO.md:71-108) regenerated with the DEVICE
+    field arithmetic: x = from(i) + from(j+5) via from_raw and add, x^(p-2) by ~380 device squarings /
+    products.  impl 0 = fr32.cuh (literal kernels), impl 1 = to_f29 / mont_fips / finalize (shipped kernel)."""
+    torch = torch_cuda
+    xs = H.fr_op(H.FR_FROM_RAW, scalars_dev(torch, [i for i in range(5) for _ in range(5)]), impl=impl)
+    ys = H.fr_op(H.FR_FROM_RAW, scalars_dev(torch, [j + 5 for _ in range(5) for j in range(5)]), impl=impl)
+    x = H.fr_op(H.FR_ADD, xs, ys, impl=impl)
+    acc = x
+    for bit in bin(P - 2)[3:]:
+        acc = H.fr_op(H.FR_SQUARE, acc, impl=impl)
+        if bit == "1":
+            acc = H.fr_op(H.FR_MUL, acc, x, impl=impl)
+    blob = to_host(acc).tobytes()
+    assert hashlib.sha256(blob).hexdigest() == MDS_SHA256
+    # x * x^-1 == one
+    one = to_host(H.fr_op(H.FR_MUL, acc, x, impl=impl)).reshape(-1, 4)
+    assert all(int_of(r) == R for r in one)
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_ark_blob_through_device_field_ops(torch_cuda, H, impl):
+    """assets/ark.bin (HOWTO.md:21-48): from_bytes_wide(SHA-512 chain) = lo*R^2 + hi*R^3 and the running
+    sum, all on the device arithmetic (the sum as a 10-step scan of batched adds)."""
+    torch = torch_cuda
+    data, lo, hi = b"poseidon-for-plonk", [], []
+    for _ in range(960):
+        data = hashlib.sha512(data).digest()
+        lo.append(int.from_bytes(data[:32], "little"))
+        hi.append(int.from_bytes(data[32:], "little"))
+    # lo / hi are arbitrary 256-bit integers (possibly >= p), exactly what the crate's from_u512 multiplies
+    r2 = H.fr_op(H.FR_FROM_RAW, scalars_dev(torch, [R]), impl=impl)               # R * R^2 / R
+    assert int_of(to_host(r2)) == R * R % P
+    r3 = H.fr_op(H.FR_SQUARE, r2, impl=impl)                                      # R^4 / R
+    wide = H.fr_op(H.FR_ADD,
+                   H.fr_op(H.FR_MUL, scalars_dev(torch, lo), r2.expand(960, 4).contiguous(), impl=impl),
+                   H.fr_op(H.FR_MUL, scalars_dev(torch, hi), r3.expand(960, 4).contiguous(), impl=impl), impl=impl)
+    # inclusive prefix sums (Hillis-Steele), then + one
+    acc, d = wide, 1
+    while d < 960:
+        nxt = acc.clone()
+        nxt[d:] = H.fr_op(H.FR_ADD, acc[d:].contiguous(), acc[:-d].contiguous(), impl=impl)
+        acc, d = nxt, 2 * d
+    one = H.fr_op(H.FR_FROM_RAW, scalars_dev(torch, [1]), impl=impl)
+    acc = H.fr_op(H.FR_ADD, acc, one.expand(960, 4).contiguous(), impl=impl)
+    assert hashlib.sha256(to_host(acc).tobytes()).hexdigest() == ARK_SHA256
+
+
+def test_fr_ops_vs_oracle_edge_values(torch_cuda, H, oracle):
+    torch = torch_cuda
+    rng = random.Random(5)
+    edge = [0, 1, 2, P - 1, P - 2, R, P - R, (1 << 255) % P, (1 << 254) - 1, 0xFFFFFFFF, P - (1 << 32),
+            0xFFFFFFFF00000000, (P - 1) // 2, (P + 1) // 2, (1 << 128) - 1]
+    a = [rng.choice(edge) if rng.random() < 0.6 else rng.randrange(P) for _ in range(700)]
+    b = [rng.choice(edge) if rng.random() < 0.6 else rng.randrange(P) for _ in range(700)]
+    da, db = scalars_dev(torch, a), scalars_dev(torch, b)
+    for impl in (0, 1):
+        got = to_host(H.fr_op(H.FR_ADD, da, db, impl=impl)).reshape(-1, 4)
+        assert [int_of(r) for r in got] == [(x + y) % P for x, y in zip(a, b)]
+        got = to_host(H.fr_op(H.FR_MUL, da, db, impl=impl)).reshape(-1, 4)
+        assert [int_of(r) for r in got] == [oracle.fr2("mul", x, y) for x, y in zip(a, b)]
+        got = to_host(H.fr_op(H.FR_SQUARE, da, impl=impl)).reshape(-1, 4)
+        assert [int_of(r) for r in got] == [oracle.fr1("square", x) for x in a]
+        got = to_host(H.fr_op(H.FR_FROM_RAW, da, impl=impl)).reshape(-1, 4)
+        assert [int_of(r) for r in got] == [x * R % P for x in a]
+
+
+# ---------------------------------------------------------------------------------------------
+# the trait's constants iterator: any cursor, all 960 constants
+# ---------------------------------------------------------------------------------------------
+def test_free_cursor_all_constants(torch_cuda, H, oracle, hades_lib):
+    torch = torch_cuda
+    inp = oracle.gen_b(31337, 5 * 200)
+    strat = H.ScalarStrategy()
+    for cur in (0, 1, 3, 7, 334, 335, 336, 700, 955):
+        buf = to_dev(torch, inp)
+        it = H.RoundConstantsIter(cur)
+        strat.add_round_key(it, buf)
+        assert it.pos == cur + 5
+        assert (to_host(buf) == oracle.add_round_key_at(inp, cur)).all(), cur
+    for cur in (2, 336, 951):
+        buf = to_dev(torch, inp)
+        strat.apply_full_round(H.RoundConstantsIter(cur), buf)
+        assert (to_host(buf) == oracle.full_round_at(inp, cur)).all(), cur
+        buf = to_dev(torch, inp)
+        strat.apply_partial_round(H.RoundConstantsIter(cur), buf)
+        assert (to_host(buf) == oracle.partial_round_at(inp, cur)).all(), cur
+    # every one of the 960 constants: state of zeros + constants = the table itself
+    zeros = torch.zeros((192, 5, 4), dtype=torch.int64, device="cuda")
+    for r in range(192):
+        strat.add_round_key(H.RoundConstantsIter(5 * r), zeros[r])
+    table = to_host(zeros).reshape(960, 4)
+    assert [int_of(t) for t in table] == [oracle.round_constant(i) for i in range(960)]
+    # exhaustion: the reference panics "Hades252 out of ARK constants" (src/strategies.rs:40)
+    buf = to_dev(torch, inp)
+    with pytest.raises(RuntimeError, match="out of ARK constants"):
+        strat.add_round_key(H.RoundConstantsIter(956), buf)
+    assert hades_lib.hades252_add_round_key_at_dev(buf.data_ptr(), 200, 956, None) == -6
+    assert hades_lib.hades252_apply_full_round_dev(buf.data_ptr(), 200, 192, None) == -6
+    assert hades_lib.hades252_add_round_key_at_dev(buf.data_ptr(), 200, -1, None) == -1
+    assert (to_host(buf) == inp).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# per-round trace: shipped (scale-tracked) kernel == literal kernel == oracle
+# ---------------------------------------------------------------------------------------------
+def test_perm_trace_fast_vs_literal_vs_oracle(torch_cuda, H, oracle):
+    torch = torch_cuda
+    rng = random.Random(9)
+    edge = [0, 1, P - 1, R, P - R, (1 << 254) - 1, 0xFFFFFFFF]
+    n = 1500
+    vals = [rng.choice(edge) if rng.random() < 0.3 else rng.randrange(P) for _ in range(5 * n)]
+    inp = np.array([l for v in vals for l in limbs_of(v)], dtype=np.uint64)
+    dev = to_dev(torch, inp)
+    fast = H.perm_trace(dev, kernel=2)
+    lit = H.perm_trace(dev, kernel=1)
+    assert (to_host(dev) == inp).all()
+    assert torch.equal(fast, lit)
+    host = fast.cpu().numpy().view(np.uint64).reshape(67, n, 20)
+    for i in (0, 1, 63, 64, 777, n - 1):
+        _, otr = oracle.perm_trace(inp[20 * i:20 * i + 20])
+        assert (host[:, i, :] == otr.reshape(67, 20)).all()
+
+
+def test_perm_trace_fast_2pow16_digest(torch_cuda, H):
+    """Round-major trace of 2^16 states: last slice == perm output; literal and fast agree by digest."""
+    torch = torch_cuda
+    n = 1 << 16
+    st = H.gen_b(5 * n, "cuda")
+    fast = H.perm_trace(st, kernel=2)
+    lit = H.perm_trace(st, kernel=1)
+    assert H.digest(fast) == H.digest(lit)
+    out = st.clone()
+    H.ScalarStrategy().perm(out)
+    assert torch.equal(fast[66].reshape(-1), out.reshape(-1))
+
+
+# ---------------------------------------------------------------------------------------------
+# variable-length sponge
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pad", [0, 1])
+def test_sponge_var_ragged_lengths(torch_cuda, H, oracle, pad):
+    """Ragged lengths 0..33 (every residue mod 4, zero-length messages, one long outlier in a wave of
+    short ones), shuffled offsets, gaps and overlaps -- vs the oracle, both padding modes."""
+    torch = torch_cuda
+    rng = random.Random(11 + pad)
+    cap = S.to_mont((1 << 64) + 7)
+    n = 1000
+    lengths = [rng.randrange(0, 34) for _ in range(n)]
+    lengths[5] = 0
+    lengths[64:128] = [1] * 63 + [33]          # a wave of short messages with one long one
+    lengths[300:364] = [0] * 64                # a wave of empty messages
+    pool = oracle.gen_b(4242, 40000)
+    offsets = [rng.randrange(0, 40000 - 34) for _ in range(n)]      # arbitrary: overlaps and gaps
+    got = H.sponge_hash_var(to_dev(torch, pool), to_dev(torch, np.array(offsets, dtype=np.uint64)),
+                            to_dev(torch, np.array(lengths, dtype=np.uint64)), cap, pad)
+    exp = oracle.sponge_var(pool, offsets, lengths, cap, pad)
+    assert (to_host(got) == exp).all()
+
+
+def test_sponge_var_equals_fixed_and_packed(torch_cuda, H, oracle):
+    torch = torch_cuda
+    cap = S.to_mont(1 << 64)
+    n, length = 777, 6
+    msgs = oracle.gen_b(99, n * length)
+    fixed = H.sponge_hash(to_dev(torch, msgs), length, cap, 1)
+    off = np.arange(n, dtype=np.uint64) * np.uint64(length)
+    var = H.sponge_hash_var(to_dev(torch, msgs), to_dev(torch, off), to_dev(torch, np.full(n, length, dtype=np.uint64)),
+                            cap, 1)
+    assert torch.equal(fixed, var)
+    assert (to_host(fixed) == oracle.sponge(msgs, length, cap, 1)).all()
+    # packed ragged (CSR-style offsets)
+    lens = np.array([(i * 7) % 13 for i in range(500)], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    pool = oracle.gen_b(5, int(lens.sum()) + 1)
+    got = H.sponge_hash_var(to_dev(torch, pool), to_dev(torch, offs), to_dev(torch, lens), cap, 1)
+    assert (to_host(got) == oracle.sponge_var(pool, offs, lens, cap, 1)).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 5 at its real size
+# ---------------------------------------------------------------------------------------------
+def _record(name, text):
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, name), "a") as f:
+        f.write(text + "\n")
+
+
+def test_config5_one_rank_shard_2pow27(torch_cuda, H, oracle):
+    """BASELINE config[4]: 2^30 permutations over 8 GPUs = 2^27 (20 GiB) per GPU.  This is rank 7's shard
+    exactly as bench.py generates it (global element offsets of rank 7), permuted in one call, then a strided
+    sample (every 2^14-th state + the first and last 64) compared bit for bit with the CPU oracle."""
+    torch = torch_cuda
+    from hades252_amd import sharding
+    n_total, world, rank = 1 << 30, 8, 7
+    b, e = sharding.shard_range(rank, world, n_total)
+    n = e - b
+    assert n == 1 << 27
+    st = torch.empty((n, 5, 4), dtype=torch.int64, device="cuda")
+    H.gen_b(5 * n, "cuda", first_elem=5 * b, out=st.view(-1, 4))
+    idx = np.unique(np.concatenate([np.arange(0, n, 1 << 14), np.arange(64), np.arange(n - 64, n)]))
+    tidx = torch.from_numpy(idx).cuda()
+    inp = st[tidx].cpu().numpy().view(np.uint64).reshape(-1)
+    # the sampled inputs are what generator B defines for those global indices
+    for k in (0, 1, len(idx) // 2, len(idx) - 1):
+        assert (inp[20 * k:20 * k + 20] == oracle.gen_b(5 * (b + int(idx[k])), 5)).all()
+    H.ScalarStrategy().perm(st)
+    got = st[tidx].cpu().numpy().view(np.uint64).reshape(-1)
+    assert (got == oracle.perm_batch(inp)).all()
+    d = H.digest(st, first_index=20 * b)
+    _record("config5_r2.txt", "rank7_shard 2^27 perms first_perm=%d sample=%d states bit-exact vs oracle; digest %s"
+            % (b, len(idx), " ".join("%016x" % x for x in d)))
+
+
+def test_config5_whole_2pow30_on_one_device(torch_cuda, H, oracle):
+    """The whole 2^30-permutation config on ONE device (160 GiB of the 288 GB), two launches inside the
+    library.  Size-independent properties: (1) split invariance -- the digest of the whole batch equals
+    the wrapping sum of the 8 shard digests computed from independently generated + permuted shards;
+    (2) a strided oracle sample across the whole range."""
+    torch = torch_cuda
+    from hades252_amd import sharding
+    free, _ = torch.cuda.mem_get_info()
+    n_total = 1 << 30
+    if free < n_total * 160 + (22 << 30):
+        pytest.skip("needs %d GiB free HBM" % ((n_total * 160 + (22 << 30)) >> 30))
+    whole = torch.empty((n_total, 5, 4), dtype=torch.int64, device="cuda")
+    H.gen_b(5 * n_total, "cuda", out=whole.view(-1, 4))
+    idx = np.unique(np.concatenate([np.arange(0, n_total, 1 << 17), np.arange(n_total - 64, n_total),
+                                    np.arange((1 << 30) - (1 << 29) - 32, (1 << 30) - (1 << 29) + 32)]))
+    tidx = torch.from_numpy(idx).cuda()
+    inp = whole[tidx].cpu().numpy().view(np.uint64).reshape(-1)
+    H.ScalarStrategy().perm(whole)
+    got = whole[tidx].cpu().numpy().view(np.uint64).reshape(-1)
+    assert (got == oracle.perm_batch(inp)).all()
+    ref = H.digest(whole)
+    del whole
+    torch.cuda.empty_cache()
+    acc = [0, 0, 0, 0]
+    for rank in range(8):
+        b, e = sharding.shard_range(rank, 8, n_total)
+        shard = torch.empty((e - b, 5, 4), dtype=torch.int64, device="cuda")
+        H.gen_b(5 * (e - b), "cuda", first_elem=5 * b, out=shard.view(-1, 4))
+        H.ScalarStrategy().perm(shard)
+        d = H.digest(shard, first_index=20 * b)
+        acc = [(x + y) & 0xFFFFFFFFFFFFFFFF for x, y in zip(acc, d)]
+        del shard
+    assert acc == ref
+    _record("config5_r2.txt", "whole 2^30 perms on one device: digest %s == sum of 8 shard digests; %d sampled states "
+            "bit-exact vs oracle" % (" ".join("%016x" % x for x in ref), len(idx)))

@@ -31,14 +31,14 @@ def test_cursor_semantics():
 def test_derived_literal_tables(oracle):
     D.check_blobs()
     ark, mds = D.literal_tables()
-    assert len(ark) == 335 and len(mds) == 25
-    for i in (0, 1, 5, 170, 334):
+    assert len(ark) == 960 and len(mds) == 25          # all of src/round_constants.rs:18
+    for i in (0, 1, 5, 170, 334, 335, 700, 959):
         assert ark[i] == oracle.round_constant(i)
     for i in range(5):
         for j in range(5):
             assert mds[5 * i + j] == oracle.mds(i, j)
     # independent derivation agrees with the spec oracle's values
-    assert D.ark_values()[:335] == S.round_constants()[:335]
+    assert D.ark_values() == S.round_constants()
     assert D.mds_values() == S.mds_matrix()
 
 

@@ -34,6 +34,8 @@ def _worker(rank, world, port, q):
     sharding.barrier()
     mx = sharding.reduce_max(1.0 + rank)
     total = sharding.reduce_sum_int(10 + rank)
+    assert sharding.reduce_min_int(1 if rank == 0 else 0) == 0 and sharding.reduce_min_int(1) == 1
+    assert sharding.gather_floats(0.5 + rank) == [0.5, 1.5]
     # shard digests add up to the whole-range digest (how bench.py combines them)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
