@@ -21,6 +21,7 @@ ERR_OUT_OF_CONSTANTS = -6
 KERNEL_DEFAULT = 0
 KERNEL_LITERAL = 1
 KERNEL_FAST = 2
+KERNEL_COOP = 3
 
 # every symbol include/hades252.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -47,6 +48,13 @@ SIGNATURES = {
     "hades252_apply_partial_round_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
     "hades252_from_bytes_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "hades252_to_bytes_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hades252_merkle_level_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_int, POINTER(c_uint64), c_int, c_void_p]),
+    "hades252_merkle_scratch_bytes": (c_size_t, [c_size_t, c_int]),
+    "hades252_merkle_root_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_size_t, POINTER(c_uint64), c_int,
+                                         c_void_p, c_void_p]),
+    "hades252_merkle_tree_bytes": (c_size_t, [c_size_t, c_int]),
+    "hades252_merkle_build_dev": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_uint64), c_int, c_void_p, c_void_p]),
+    "hades252_merkle_open_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "hades252_merkle4_level_dev": (c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_uint64), c_int, c_void_p]),
     "hades252_merkle4_scratch_bytes": (c_size_t, [c_size_t]),
     "hades252_merkle4_root_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, POINTER(c_uint64), c_int,

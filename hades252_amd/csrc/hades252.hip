@@ -15,6 +15,7 @@
 #include "hades_literal.cuh"
 #include "staging.cuh"
 #include "hades_fast.cuh"
+#include "hades_coop.cuh"
 
 using namespace hades;
 
@@ -30,8 +31,12 @@ __device__ const uint32_t d_r2[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b
                                      0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
 
 __device__ const FastTables d_fast = {HADES_FAST_ROUND_INIT, HADES_FAST_FINAL_F};
+// low-latency schedule (hades_coop.cuh)
+__device__ const CoopTables d_coop = {HADES_COOP_ROUND_INIT, HADES_COOP_FINAL_F, HADES_FAST_MDS_SMALL};
 // trace kernel: U_r with mont(X_after_round_r, U_r) = x * 2^256
 __device__ const int32_t d_trace_u[67][16] = HADES_FAST_TRACE_U_INIT;
+// ... + D_r: the partial-round constants of words 0..3 that the shipped schedule defers (hades_fast.cuh item 5)
+__device__ const uint32_t d_trace_d[67][5][8] = HADES_FAST_TRACE_D_INIT;
 // generic radix-2^29 field ops (hades252_fr_op_dev)
 __device__ const int32_t d_rp_mod_p[16] = HADES_RP_MOD_P29;
 __device__ const int32_t d_rp2_over_r[16] = HADES_RP2_OVER_R29;
@@ -88,8 +93,9 @@ __global__ void __launch_bounds__(kBlock) k_perm_trace_literal(const uint8_t *__
 
 // Scale-tracked trace (the shipped one): the rounds of k_perm_fast; after each round every word is
 // brought back to the in-memory BlsScalar with ONE constant product (U_r = 2^256 * Rp / s_{r+1},
-// hades252_amd/_derive.py) and a full reduction -- 5 extra products per round instead of the literal
-// schedule's 28 / 40 full-width products.
+// hades252_amd/_derive.py), a full reduction, and -- in partial rounds, whose word 0..3 constants the
+// schedule defers -- one field addition of the known offset D_r: 5 extra products per round instead of
+// the literal schedule's 28 / 40 full-width products.
 __global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__restrict__ states,
                                                                uint8_t *__restrict__ trace, size_t n) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -107,7 +113,11 @@ __global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__
         fast_round(d_fast.round[r], r < 4 || r >= 63, st);
         const int32_t *u = d_trace_u[r];
 #pragma unroll
-        for (int w = 0; w < 5; w++) slab_put<5>(slab, w, finalize(mont_mul_const(st[w], u)));
+        for (int w = 0; w < 5; w++) {
+            Fr v = finalize(mont_mul_const(st[w], u));
+            if (r >= 4 && r < 63) v = fr_add(v, load_const(d_trace_d[r], w));
+            slab_put<5>(slab, w, v);
+        }
         slab_flush<5>(trace + (size_t)r * n * 160, rec0, n, slab);
     }
 }
@@ -213,18 +223,174 @@ __global__ void __launch_bounds__(kBlock, HADES_FAST_MINW) k_perm_fast(uint8_t *
     wave_store_records<5>(states, rec0, n, slab, out);
 }
 
-__global__ void __launch_bounds__(kBlock, 4) k_merkle4_level_fast(const uint8_t *__restrict__ children,
-                                                               uint8_t *__restrict__ parents, size_t n_parents,
-                                                               Fr tag, int out_idx) {
+// One Merkle level, one parent per lane: parent = perm([tag, c_0 .. c_{ARITY-1}, 0 ..])[out_idx]
+// (arity 4 fills the state: the caller shape of dusk-poseidon, README.md:9; arity 2 leaves two zero words).
+template <int ARITY>
+__global__ void __launch_bounds__(kBlock, 4) k_merkle_level_fast(const uint8_t *__restrict__ children,
+                                                                 uint8_t *__restrict__ parents, size_t n_parents,
+                                                                 Fr tag, int out_idx) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t *slab = wave_slab<4>(lds);
+    uint8_t *slab = wave_slab<ARITY>(lds);
     size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
-    Fr ch[4];
-    wave_load_records<4>(children, rec0, n_parents, slab, ch);
-    Fr st[5] = {tag, ch[0], ch[1], ch[2], ch[3]};
+    Fr ch[ARITY];
+    wave_load_records<ARITY>(children, rec0, n_parents, slab, ch);
+    Fr st[5];
+    st[0] = tag;
+#pragma unroll
+    for (int w = 1; w < 5; w++) {
+        if (w <= ARITY) {
+            st[w] = ch[w <= ARITY ? w - 1 : 0];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) st[w].l[i] = 0;
+        }
+    }
     Fr out[1];
     fast_perm<1>(&d_fast, st, out, out_idx);
     wave_store_records<1>(parents, rec0, n_parents, slab, out);
+}
+
+// ---- low-latency kernels: five waves per state (hades_coop.cuh) --------------------------------------
+// In-place permutation of up to 64 states per 320-thread block.
+__global__ void __launch_bounds__(kCoopThreads) k_perm_coop(uint8_t *states, size_t n) {
+    __shared__ CoopLds L;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & (kWave - 1);
+    const size_t rec0 = (size_t)blockIdx.x * kCoopStates;
+    const size_t total = n * 10, chunk0 = rec0 * 10;
+    uint4 *g = reinterpret_cast<uint4 *>(states + rec0 * 160);
+#pragma unroll
+    for (int c = threadIdx.x; c < kCoopStates * 10; c += kCoopThreads) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (chunk0 + c < total) v = g[c];
+        const int rec = c / 10, part = c - rec * 10;
+        *reinterpret_cast<uint4 *>(L.stage + rec * 176 + part * 16) = v;
+    }
+    __syncthreads();
+    Fr w;
+    {
+        const uint4 *p = reinterpret_cast<const uint4 *>(L.stage + lane * 176 + wv * 32);
+        uint4 lo = p[0], hi = p[1];
+        w.l[0] = lo.x; w.l[1] = lo.y; w.l[2] = lo.z; w.l[3] = lo.w;
+        w.l[4] = hi.x; w.l[5] = hi.y; w.l[6] = hi.z; w.l[7] = hi.w;
+    }
+    const F29 fin = coop_rounds(&d_coop, L, wv, to_f29(w));     // 67 barriers: everyone has read `stage` by now
+    const Fr o = coop_finish(&d_coop, fin);
+    {
+        uint4 *p = reinterpret_cast<uint4 *>(L.stage + lane * 176 + wv * 32);
+        p[0] = make_uint4(o.l[0], o.l[1], o.l[2], o.l[3]);
+        p[1] = make_uint4(o.l[4], o.l[5], o.l[6], o.l[7]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = threadIdx.x; c < kCoopStates * 10; c += kCoopThreads) {
+        const int rec = c / 10, part = c - rec * 10;
+        uint4 v = *reinterpret_cast<const uint4 *>(L.stage + rec * 176 + part * 16);
+        if (chunk0 + c < total) g[c] = v;
+    }
+}
+
+// Fused Merkle levels: block b takes the children of parents [64b, 64b + 64) of one level (n_parents in
+// all) and runs `n_levels` tree levels without leaving the CU: level j has 64 / ARITY^j parents per block,
+// its digests become the next level's children through LDS.  The caller guarantees that the block's parent
+// count is divisible by ARITY^(n_levels-1) (trees with a power-of-ARITY leaf count are).
+//   out_all  (may be NULL) receives EVERY level: level j (n_parents / ARITY^j digests of 32 B) at byte offset
+//            32 * sum_{i<j} n_parents / ARITY^i  -- the layout of hades252_merkle_build_dev;
+//   out_last (may be NULL) receives the last level run: n_parents / ARITY^(n_levels-1) digests.
+template <int ARITY>
+__global__ void __launch_bounds__(kCoopThreads) k_merkle_coop(const uint8_t *__restrict__ children,
+                                                             uint8_t *__restrict__ out_all,
+                                                             uint8_t *__restrict__ out_last, size_t n_parents, Fr tag,
+                                                             int out_idx, int n_levels) {
+    __shared__ CoopLds L;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & (kWave - 1);
+    const size_t par0 = (size_t)blockIdx.x * kCoopStates;
+    int valid = (int)(n_parents - par0 < (size_t)kCoopStates ? n_parents - par0 : (size_t)kCoopStates);
+    // children of this block: valid * ARITY digests, contiguous -> stage[child index * 32]
+    {
+        const uint4 *g = reinterpret_cast<const uint4 *>(children + par0 * ARITY * 32);
+        const int chunks = valid * ARITY * 2;
+#pragma unroll
+        for (int c = threadIdx.x; c < kCoopStates * ARITY * 2; c += kCoopThreads)
+            if (c < chunks) *reinterpret_cast<uint4 *>(L.stage + c * 16) = g[c];
+    }
+    __syncthreads();
+    size_t level_off = 0;                    // byte offset of the current level inside out_all
+    size_t level_n = n_parents;              // digests in the current level (whole tree level)
+    size_t blk_first = par0;                 // index of this block's first digest in the current level
+#pragma unroll 1
+    for (int j = 0; j < n_levels; j++) {
+        Fr w;
+        if (wv == 0) {
+            w = tag;
+        } else if (wv <= ARITY) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(L.stage + (lane * ARITY + (wv - 1)) * 32);
+            uint4 lo = p[0], hi = p[1];
+            w.l[0] = lo.x; w.l[1] = lo.y; w.l[2] = lo.z; w.l[3] = lo.w;
+            w.l[4] = hi.x; w.l[5] = hi.y; w.l[6] = hi.z; w.l[7] = hi.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) w.l[i] = 0;
+        }
+        const F29 fin = coop_rounds(&d_coop, L, wv, to_f29(w));   // barriers inside: `stage` has been read
+        if (wv == out_idx) {
+            const Fr o = coop_finish(&d_coop, fin);
+            if (lane < valid) {
+                const uint4 lo = make_uint4(o.l[0], o.l[1], o.l[2], o.l[3]);
+                const uint4 hi = make_uint4(o.l[4], o.l[5], o.l[6], o.l[7]);
+                uint4 *p = reinterpret_cast<uint4 *>(L.stage + lane * 32);
+                p[0] = lo;
+                p[1] = hi;
+                if (out_all != nullptr) {
+                    uint4 *q = reinterpret_cast<uint4 *>(out_all + level_off + (blk_first + lane) * 32);
+                    q[0] = lo;
+                    q[1] = hi;
+                }
+                if (out_last != nullptr && j == n_levels - 1) {
+                    uint4 *q = reinterpret_cast<uint4 *>(out_last + (blk_first + lane) * 32);
+                    q[0] = lo;
+                    q[1] = hi;
+                }
+            }
+        }
+        __syncthreads();
+        level_off += level_n * 32;
+        level_n /= ARITY;
+        blk_first /= ARITY;
+        valid /= ARITY;
+    }
+}
+
+// Openings (authentication paths): for query t with leaf index idx, level l = 0 .. depth-1, the ARITY-1
+// siblings of the path node at that level, in child order with the path node's own position skipped:
+//   paths[t][l][s] (32 B each).  Level 0 siblings are leaves, level l >= 1 siblings are digests of tree level
+//   l-1 (layout of hades252_merkle_build_dev).  One thread per 16-byte half digest.
+template <int ARITY>
+__global__ void __launch_bounds__(kBlock) k_merkle_open(const uint8_t *__restrict__ leaves,
+                                                        const uint8_t *__restrict__ tree, size_t n_leaves, int depth,
+                                                        const uint64_t *__restrict__ indices, size_t n_queries,
+                                                        uint8_t *__restrict__ paths) {
+    const size_t per_query = (size_t)depth * (ARITY - 1) * 2;
+    const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (tid >= n_queries * per_query) return;
+    const size_t t = tid / per_query;
+    const int rem = (int)(tid - t * per_query);
+    const int l = rem / ((ARITY - 1) * 2), sh = rem - l * (ARITY - 1) * 2, s = sh >> 1, half = sh & 1;
+    size_t node = indices[t];                 // index of the path node at level l (level 0 = leaves)
+    const uint8_t *level = leaves;
+    size_t level_n = n_leaves, off = 0;
+    for (int i = 0; i < l; i++) {
+        node /= ARITY;
+        level_n /= ARITY;
+        level = tree + off;
+        off += level_n * 32;
+    }
+    const size_t first = node - node % ARITY;
+    const int pos = (int)(node % ARITY);
+    const int sib = s < pos ? s : s + 1;
+    const uint4 v = *reinterpret_cast<const uint4 *>(level + (first + sib) * 32 + half * 16);
+    *reinterpret_cast<uint4 *>(paths + tid * 16) = v;
 }
 
 // Batched sponge over the permutation (the caller shape of dusk-poseidon's sponge hash, reference
@@ -234,10 +400,17 @@ __global__ void __launch_bounds__(kBlock, 4) k_merkle4_level_fast(const uint8_t 
 // of 4 scalars is added to words 1..4 and followed by a permutation; pad_mode 1 appends a single 1
 // (then zeros) first; at least one permutation.  Digest = word 1.
 //   * variable length: `offsets` / `lengths` per message (NULL: message i = [i*fixed_len, (i+1)*fixed_len));
-//     every lane runs to the block-wide maximum block count and latches its digest after its own last
-//     block (later permutations of that lane work on don't-care data).
+//     every lane runs to its WAVE's maximum block count and latches its digest after its own last block
+//     (later permutations of that lane work on don't-care data).  Callers with very ragged batches should
+//     bucket messages by block count so that the 64 messages of a wave are alike.
 //   * message blocks are staged through the wave's LDS slab: 8 lanes fetch the 128 contiguous bytes of one
 //     message block, 8 messages per load instruction -- no lane walks HBM with a message-sized stride.
+// orders this wave's LDS traffic (other lanes' slab writes before my reads, my reads before the next writes)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
     uint32_t lo = __shfl((uint32_t)v, src, kWave), hi = __shfl((uint32_t)(v >> 32), src, kWave);
     return ((uint64_t)hi << 32) | lo;
@@ -249,7 +422,6 @@ __global__ void __launch_bounds__(kBlock, 3) k_sponge(const uint8_t *__restrict_
                                                       uint8_t *__restrict__ digests, size_t n_msgs, size_t fixed_len,
                                                       Fr capacity, int pad_mode) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    __shared__ unsigned long long wave_max[kWavesPerBlock];
     uint8_t *slab = wave_slab<4>(lds);
     constexpr int kRec = lds_rec_bytes(4);
     const int lane = threadIdx.x & (kWave - 1);
@@ -261,17 +433,14 @@ __global__ void __launch_bounds__(kBlock, 3) k_sponge(const uint8_t *__restrict_
     uint64_t blocks = (len + (pad_mode == 1 ? 1 : 0) + 3) / 4;
     if (blocks == 0) blocks = 1;
     if (!live) blocks = 0;
-    // block-uniform trip count (the staging below uses block-wide barriers)
+    // wave-uniform trip count: the slab is wave-private and a wave's LDS operations execute in order, so the
+    // staging below needs no block-wide barrier (only compiler fences)
     uint64_t mx = blocks;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         uint64_t other = shfl_u64(mx, lane ^ o);
         mx = other > mx ? other : mx;
     }
-    if (lane == 0) wave_max[threadIdx.x / kWave] = mx;
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < kWavesPerBlock; w++) mx = wave_max[w] > mx ? wave_max[w] : mx;
 
     Fr one_mont;                               // 1 * 2^256 mod p
     {
@@ -299,7 +468,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_sponge(const uint8_t *__restrict_
             if (idx < mlen) v = *reinterpret_cast<const uint4 *>(scalars + (moff + idx) * 32 + (part & 1) * 16);
             *reinterpret_cast<uint4 *>(slab + m * kRec + part * 16) = v;
         }
-        __syncthreads();
+        wave_lds_fence();
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint4 *p = reinterpret_cast<const uint4 *>(slab + lane * kRec + k * 32);
@@ -310,7 +479,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_sponge(const uint8_t *__restrict_
             if (pad_mode == 1 && 4 * t + k == len) v = one_mont;      // staged value is zero there
             st[1 + k] = fr_add(st[1 + k], v);
         }
-        __syncthreads();
+        wave_lds_fence();
         Fr out[5];
         fast_perm<5>(&d_fast, st, out, 0);
 #pragma unroll
@@ -407,11 +576,38 @@ static int launch_perm_fast(uint8_t *states, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_perm_fast, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, states, n);
     return HADES252_OK;
 }
-static int launch_merkle4_level_fast(const uint8_t *children, uint8_t *parents, size_t n, Fr tag, int out_idx,
-                                     hipStream_t s) {
-    hipLaunchKernelGGL(k_merkle4_level_fast, dim3(blocks_for(n)), dim3(kBlock), lds_for(4), s, children, parents, n,
-                       tag, out_idx);
-    return HADES252_OK;
+static Fr fr_from_u64(const uint64_t v[4]) {
+    Fr r;
+    for (int k = 0; k < 4; k++) {
+        r.l[2 * k] = (uint32_t)v[k];
+        r.l[2 * k + 1] = (uint32_t)(v[k] >> 32);
+    }
+    return r;
+}
+
+// a batch this small is latency-bound: the five-waves-per-state kernel finishes it in less than half the time
+// of one per-lane wave (crossover measured on MI355X: profiles/r2/time_paths.txt)
+static constexpr size_t kCoopMaxStates = (size_t)1 << 14;
+
+static void launch_merkle_level(int arity, const uint8_t *children, uint8_t *parents, size_t n, Fr tag, int out_idx,
+                                hipStream_t s) {
+    if (arity == 4)
+        hipLaunchKernelGGL(k_merkle_level_fast<4>, dim3(blocks_for(n)), dim3(kBlock), lds_for(4), s, children, parents,
+                           n, tag, out_idx);
+    else
+        hipLaunchKernelGGL(k_merkle_level_fast<2>, dim3(blocks_for(n)), dim3(kBlock), lds_for(2), s, children, parents,
+                           n, tag, out_idx);
+}
+
+static void launch_merkle_coop(int arity, const uint8_t *children, uint8_t *out_all, uint8_t *out_last, size_t n_parents,
+                               Fr tag, int out_idx, int n_levels, hipStream_t s) {
+    const unsigned grid = (unsigned)((n_parents + kCoopStates - 1) / kCoopStates);
+    if (arity == 4)
+        hipLaunchKernelGGL(k_merkle_coop<4>, dim3(grid), dim3(kCoopThreads), 0, s, children, out_all, out_last,
+                           n_parents, tag, out_idx, n_levels);
+    else
+        hipLaunchKernelGGL(k_merkle_coop<2>, dim3(grid), dim3(kCoopThreads), 0, s, children, out_all, out_last,
+                           n_parents, tag, out_idx, n_levels);
 }
 
 static int check_device() {
@@ -461,10 +657,14 @@ int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int
     if (d_states == nullptr || misaligned(d_states)) return HADES252_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     uint8_t *p = (uint8_t *)d_states;
-    if (kernel == HADES252_KERNEL_DEFAULT) kernel = HADES252_KERNEL_FAST;
+    // small batches are latency-bound: five waves per state (hades_coop.cuh); large ones one state per lane
+    if (kernel == HADES252_KERNEL_DEFAULT) kernel = n_perms <= kCoopMaxStates ? HADES252_KERNEL_COOP : HADES252_KERNEL_FAST;
     for (size_t off = 0; off < n_perms; off += kMaxLaunchRecords) {
         size_t n = n_perms - off < kMaxLaunchRecords ? n_perms - off : kMaxLaunchRecords;
-        if (kernel == HADES252_KERNEL_LITERAL) {
+        if (kernel == HADES252_KERNEL_COOP) {
+            hipLaunchKernelGGL(k_perm_coop, dim3((unsigned)((n + kCoopStates - 1) / kCoopStates)), dim3(kCoopThreads), 0,
+                               s, p + off * 160, n);
+        } else if (kernel == HADES252_KERNEL_LITERAL) {
             hipLaunchKernelGGL(k_states_literal<OP_PERM>, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s,
                                p + off * 160, n, 0);
         } else if (kernel == HADES252_KERNEL_FAST) {
@@ -793,22 +993,38 @@ int hades252_to_bytes_dev(const void *d_limbs, void *d_bytes, size_t n_scalars, 
 }
 
 // ---- Merkle ----------------------------------------------------------------------------------
-int hades252_merkle4_level_dev(const void *d_children, void *d_parents, size_t n_parents, const uint64_t tag_mont[4],
-                               int out_idx, void *stream) {
+static int log_arity(size_t n, int arity) {          // n = arity^k -> k, else -1
+    if (arity != 2 && arity != 4) return -1;
+    int k = 0;
+    while (n > 1) {
+        if (n % arity) return -1;
+        n /= arity;
+        k++;
+    }
+    return n == 1 ? k : -1;
+}
+
+int hades252_merkle_level_dev(const void *d_children, void *d_parents, size_t n_parents, int arity,
+                              const uint64_t tag_mont[4], int out_idx, void *stream) {
+    if (arity != 2 && arity != 4) return HADES252_ERR_INVALID_ARG;
     if (n_parents == 0) return HADES252_OK;
     if (d_children == nullptr || d_parents == nullptr || tag_mont == nullptr || out_idx < 0 || out_idx >= 5 ||
         n_parents > kMaxLaunchRecords || misaligned(d_children) || misaligned(d_parents))
         return HADES252_ERR_INVALID_ARG;
-    Fr tag;
-    for (int k = 0; k < 4; k++) {
-        tag.l[2 * k] = (uint32_t)tag_mont[k];
-        tag.l[2 * k + 1] = (uint32_t)(tag_mont[k] >> 32);
-    }
-    int rc = launch_merkle4_level_fast((const uint8_t *)d_children, (uint8_t *)d_parents, n_parents, tag, out_idx,
-                                       (hipStream_t)stream);
-    if (rc != HADES252_OK) return rc;
+    const Fr tag = fr_from_u64(tag_mont);
+    if (n_parents <= kCoopMaxStates)
+        launch_merkle_coop(arity, (const uint8_t *)d_children, nullptr, (uint8_t *)d_parents, n_parents, tag, out_idx, 1,
+                           (hipStream_t)stream);
+    else
+        launch_merkle_level(arity, (const uint8_t *)d_children, (uint8_t *)d_parents, n_parents, tag, out_idx,
+                            (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return HADES252_OK;
+}
+
+int hades252_merkle4_level_dev(const void *d_children, void *d_parents, size_t n_parents, const uint64_t tag_mont[4],
+                               int out_idx, void *stream) {
+    return hades252_merkle_level_dev(d_children, d_parents, n_parents, 4, tag_mont, out_idx, stream);
 }
 
 static int sponge_launch(const void *d_scalars, const uint64_t *d_offsets, const uint64_t *d_lengths, size_t n_msgs,
@@ -844,35 +1060,107 @@ int hades252_sponge_hash_var_dev(const void *d_scalars, const uint64_t *d_offset
     return sponge_launch(d_scalars, d_offsets, d_lengths, n_msgs, 0, capacity_mont, pad_mode, d_digests, stream);
 }
 
-static bool is_pow4(size_t n) { return n >= 4 && (n & (n - 1)) == 0 && (__builtin_ctzll(n) % 2) == 0; }
+size_t hades252_merkle_tree_bytes(size_t n_leaves, int arity) {
+    if (log_arity(n_leaves, arity) < 1) return 0;
+    return (n_leaves - 1) / (size_t)(arity - 1) * 32;          // n/A + n/A^2 + ... + 1 digests
+}
 
-size_t hades252_merkle4_scratch_bytes(size_t n_leaves) {
-    // two ping-pong buffers: level 1 (n/4 nodes) and level 2 (n/16 nodes)
-    if (!is_pow4(n_leaves)) return 0;
-    size_t a = (n_leaves / 4) * 32, b = (n_leaves >= 16 ? n_leaves / 16 : 1) * 32;
-    return a + b;
+size_t hades252_merkle_scratch_bytes(size_t n_leaves, int arity) {
+    // two ping-pong buffers: level 1 (n/A digests) and level 2 (n/A^2); a single-level tree needs none
+    if (log_arity(n_leaves, arity) < 2) return 0;
+    return (n_leaves / arity) * 32 + (n_leaves / arity / arity) * 32;
+}
+size_t hades252_merkle4_scratch_bytes(size_t n_leaves) { return hades252_merkle_scratch_bytes(n_leaves, 4); }
+
+// The whole tree.  Levels with more than kCoopMaxStates parents run one parent per lane (throughput);
+// from there on the five-waves-per-state kernel takes 64 parents per block through up to log_A(64) + 1 levels
+// inside the CU (k_merkle_coop) -- a 65 536-leaf arity-4 tree is two launches.
+// tree != NULL: every level is kept (layout of hades252_merkle_build_dev); else ping-pong in buf_a / buf_b.
+static int merkle_run(const uint8_t *leaves, size_t n_leaves, int arity, uint8_t *tree, uint8_t *buf_a, uint8_t *buf_b,
+                      uint8_t *root, const Fr &tag, int out_idx, hipStream_t s) {
+    const int per_block_levels = log_arity(kCoopStates, arity) + 1;       // 64 parents -> 1 digest
+    const uint8_t *src = leaves;
+    size_t n = n_leaves, off = 0;
+    bool to_a = true;
+    while (n > 1) {
+        const size_t parents = n / arity;
+        uint8_t *dst_pp = to_a ? buf_a : buf_b;
+        if (parents > kCoopMaxStates) {
+            uint8_t *dst = tree != nullptr ? tree + off : dst_pp;
+            launch_merkle_level(arity, src, dst, parents, tag, out_idx, s);
+            HIP_TRY(hipGetLastError());
+            off += parents * 32;
+            src = dst;
+            n = parents;
+        } else {
+            const int n_levels = parents < (size_t)kCoopStates ? log_arity(parents, arity) + 1 : per_block_levels;
+            size_t last_n = parents, span = 0;                    // digests in the last level run; bytes before it
+            for (int j = 1; j < n_levels; j++) {
+                span += last_n * 32;
+                last_n /= arity;
+            }
+            uint8_t *out_all = tree != nullptr ? tree + off : nullptr;
+            uint8_t *out_last = last_n == 1 ? root : (tree != nullptr ? nullptr : dst_pp);
+            launch_merkle_coop(arity, src, out_all, out_last, parents, tag, out_idx, n_levels, s);
+            HIP_TRY(hipGetLastError());
+            src = tree != nullptr ? tree + off + span : dst_pp;
+            off += span + last_n * 32;
+            n = last_n;
+        }
+        to_a = !to_a;
+    }
+    return HADES252_OK;
+}
+
+int hades252_merkle_root_dev(const void *d_leaves, size_t n_leaves, int arity, void *d_scratch, size_t scratch_bytes,
+                             const uint64_t tag_mont[4], int out_idx, void *d_root, void *stream) {
+    if (d_leaves == nullptr || d_root == nullptr || tag_mont == nullptr || log_arity(n_leaves, arity) < 1 ||
+        out_idx < 0 || out_idx >= 5 || misaligned(d_leaves) || misaligned(d_root))
+        return HADES252_ERR_INVALID_ARG;
+    const size_t need = hades252_merkle_scratch_bytes(n_leaves, arity);
+    if (need > 0 && (d_scratch == nullptr || scratch_bytes < need)) return HADES252_ERR_SCRATCH;
+    if (need > 0 && misaligned(d_scratch)) return HADES252_ERR_INVALID_ARG;
+    uint8_t *buf_a = (uint8_t *)d_scratch;
+    uint8_t *buf_b = need > 0 ? buf_a + (n_leaves / arity) * 32 : nullptr;
+    return merkle_run((const uint8_t *)d_leaves, n_leaves, arity, nullptr, buf_a, buf_b, (uint8_t *)d_root,
+                      fr_from_u64(tag_mont), out_idx, (hipStream_t)stream);
 }
 
 int hades252_merkle4_root_dev(const void *d_leaves, size_t n_leaves, void *d_scratch, size_t scratch_bytes,
                               const uint64_t tag_mont[4], int out_idx, void *d_root, void *stream) {
-    if (d_leaves == nullptr || d_root == nullptr || tag_mont == nullptr || !is_pow4(n_leaves))
+    return hades252_merkle_root_dev(d_leaves, n_leaves, 4, d_scratch, scratch_bytes, tag_mont, out_idx, d_root, stream);
+}
+
+int hades252_merkle_build_dev(const void *d_leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
+                              void *d_tree, void *stream) {
+    if (d_leaves == nullptr || d_tree == nullptr || tag_mont == nullptr || log_arity(n_leaves, arity) < 1 ||
+        out_idx < 0 || out_idx >= 5 || misaligned(d_leaves) || misaligned(d_tree))
         return HADES252_ERR_INVALID_ARG;
-    if (scratch_bytes < hades252_merkle4_scratch_bytes(n_leaves) || (d_scratch == nullptr && n_leaves > 4))
-        return HADES252_ERR_SCRATCH;
-    uint8_t *buf_a = (uint8_t *)d_scratch;
-    uint8_t *buf_b = buf_a + (n_leaves / 4) * 32;
-    const uint8_t *src = (const uint8_t *)d_leaves;
-    size_t n = n_leaves;
-    bool to_a = true;
-    while (n > 1) {
-        size_t parents = n / 4;
-        uint8_t *dst = parents == 1 ? (uint8_t *)d_root : (to_a ? buf_a : buf_b);
-        int rc = hades252_merkle4_level_dev(src, dst, parents, tag_mont, out_idx, stream);
-        if (rc != HADES252_OK) return rc;
-        src = dst;
-        n = parents;
-        to_a = !to_a;
-    }
+    uint8_t *tree = (uint8_t *)d_tree;
+    uint8_t *root = tree + hades252_merkle_tree_bytes(n_leaves, arity) - 32;
+    return merkle_run((const uint8_t *)d_leaves, n_leaves, arity, tree, nullptr, nullptr, root, fr_from_u64(tag_mont),
+                      out_idx, (hipStream_t)stream);
+}
+
+int hades252_merkle_open_dev(const void *d_leaves, const void *d_tree, size_t n_leaves, int arity,
+                             const uint64_t *d_indices, size_t n_queries, void *d_paths, void *stream) {
+    const int depth = log_arity(n_leaves, arity);
+    if (depth < 1) return HADES252_ERR_INVALID_ARG;
+    if (n_queries == 0) return HADES252_OK;
+    if (d_leaves == nullptr || d_tree == nullptr || d_indices == nullptr || d_paths == nullptr || misaligned(d_leaves) ||
+        misaligned(d_tree) || misaligned(d_paths))
+        return HADES252_ERR_INVALID_ARG;
+    const size_t threads = n_queries * (size_t)depth * (arity - 1) * 2;
+    if (threads > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    if (arity == 4)
+        hipLaunchKernelGGL(k_merkle_open<4>, dim3(blocks_for(threads)), dim3(kBlock), 0, (hipStream_t)stream,
+                           (const uint8_t *)d_leaves, (const uint8_t *)d_tree, n_leaves, depth, d_indices, n_queries,
+                           (uint8_t *)d_paths);
+    else
+        hipLaunchKernelGGL(k_merkle_open<2>, dim3(blocks_for(threads)), dim3(kBlock), 0, (hipStream_t)stream,
+                           (const uint8_t *)d_leaves, (const uint8_t *)d_tree, n_leaves, depth, d_indices, n_queries,
+                           (uint8_t *)d_paths);
+    HIP_TRY(hipGetLastError());
     return HADES252_OK;
 }
 

@@ -270,33 +270,86 @@ def _tag_arr(tag_mont: int):
     return (ctypes.c_uint64 * 4)(*[(tag_mont >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)])
 
 
-def merkle4_level(children_t, tag_mont: int, out_idx: int = 1):
-    """One arity-4 level: parent = perm([tag, c0, c1, c2, c3])[out_idx]."""
+def _check_arity_pow(n: int, arity: int, what: str) -> int:
+    if arity not in (2, 4):
+        raise ValueError("%s: arity must be 2 or 4" % what)
+    depth, m = 0, n
+    while m > 1 and m % arity == 0:
+        m //= arity
+        depth += 1
+    if m != 1 or depth < 1:
+        raise ValueError("%s: n_leaves must be a power of %d (>= %d)" % (what, arity, arity))
+    return depth
+
+
+def merkle_level(children_t, arity: int, tag_mont: int, out_idx: int = 1):
+    """One tree level: parent = perm([tag, c_0 .. c_{arity-1}, 0 ..])[out_idx]."""
     import torch
-    ptr, n, dev = _dev_buffer(children_t, 128, "merkle4_level")
+    if arity not in (2, 4):
+        raise ValueError("merkle_level: arity must be 2 or 4")
+    ptr, n, dev = _dev_buffer(children_t, 32 * arity, "merkle_level")
     parents = torch.empty((n, 4), dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.lib().hades252_merkle4_level_dev(ptr, parents.data_ptr(), n, _tag_arr(tag_mont), out_idx,
-                                                    _stream_ptr(dev)), "merkle4_level")
+        check(_lib.lib().hades252_merkle_level_dev(ptr, parents.data_ptr(), n, arity, _tag_arr(tag_mont), out_idx,
+                                                   _stream_ptr(dev)), "merkle_level")
     return parents
 
 
-def merkle4_root(leaves_t, tag_mont: int, out_idx: int = 1, scratch=None):
-    """Root of the arity-4 tree over ``leaves_t`` (n_leaves x 32 B, n_leaves a power of 4)."""
+def merkle_root(leaves_t, arity: int, tag_mont: int, out_idx: int = 1, scratch=None):
+    """Root of the arity-`arity` tree over ``leaves_t`` (n_leaves x 32 B, n_leaves a power of arity)."""
     import torch
-    ptr, n, dev = _dev_buffer(leaves_t, 32, "merkle4_root")
-    need = _lib.lib().hades252_merkle4_scratch_bytes(n)
-    if need == 0:
-        raise ValueError("merkle4_root: n_leaves must be a power of 4 (>= 4)")
+    ptr, n, dev = _dev_buffer(leaves_t, 32, "merkle_root")
+    _check_arity_pow(n, arity, "merkle_root")
+    need = _lib.lib().hades252_merkle_scratch_bytes(n, arity)
     if scratch is None:
-        scratch = torch.empty(need // 8, dtype=torch.int64, device=dev)
+        scratch = torch.empty(max(need // 8, 2), dtype=torch.int64, device=dev)
     sptr = scratch.data_ptr()
     sbytes = scratch.numel() * scratch.element_size()
     root = torch.empty(4, dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.lib().hades252_merkle4_root_dev(ptr, n, sptr, sbytes, _tag_arr(tag_mont), out_idx,
-                                                   root.data_ptr(), _stream_ptr(dev)), "merkle4_root")
+        check(_lib.lib().hades252_merkle_root_dev(ptr, n, arity, sptr, sbytes, _tag_arr(tag_mont), out_idx,
+                                                  root.data_ptr(), _stream_ptr(dev)), "merkle_root")
     return root
+
+
+def merkle_build(leaves_t, arity: int, tag_mont: int, out_idx: int = 1):
+    """Every level of the tree: [(n-1)/(arity-1), 4] int64 -- level 1 first, the root last."""
+    import torch
+    ptr, n, dev = _dev_buffer(leaves_t, 32, "merkle_build")
+    _check_arity_pow(n, arity, "merkle_build")
+    tree = torch.empty(((n - 1) // (arity - 1), 4), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_merkle_build_dev(ptr, n, arity, _tag_arr(tag_mont), out_idx, tree.data_ptr(),
+                                                   _stream_ptr(dev)), "merkle_build")
+    return tree
+
+
+def merkle_open(leaves_t, tree_t, arity: int, indices_t):
+    """Authentication paths: [n_queries, depth, arity-1, 4] int64 (siblings in child order, the path node's
+    own position (index // arity^l) % arity skipped)."""
+    import torch
+    ptr, n, dev = _dev_buffer(leaves_t, 32, "merkle_open")
+    depth = _check_arity_pow(n, arity, "merkle_open")
+    tptr, nt, _ = _dev_buffer(tree_t, 32, "merkle_open")
+    if nt != (n - 1) // (arity - 1):
+        raise ValueError("merkle_open: tree buffer does not belong to %d leaves" % n)
+    iptr, nq, _ = _dev_buffer(indices_t, 8, "merkle_open")
+    if nq and int(indices_t.max().item()) >= n:
+        raise IndexError("merkle_open: leaf index out of range")
+    paths = torch.empty((nq, depth, arity - 1, 4), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_merkle_open_dev(ptr, tptr, n, arity, iptr, nq, paths.data_ptr(), _stream_ptr(dev)),
+              "merkle_open")
+    return paths
+
+
+def merkle4_level(children_t, tag_mont: int, out_idx: int = 1):
+    return merkle_level(children_t, 4, tag_mont, out_idx)
+
+
+def merkle4_root(leaves_t, tag_mont: int, out_idx: int = 1, scratch=None):
+    """Root of the arity-4 tree over ``leaves_t`` (BASELINE config 4)."""
+    return merkle_root(leaves_t, 4, tag_mont, out_idx, scratch)
 
 
 def sponge_hash(msgs_t, msg_len: int, capacity_mont: int, pad_mode: int = 1):

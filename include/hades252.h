@@ -58,7 +58,9 @@ extern "C" {
 /* kernel selectors for hades252_perm_batch_dev_ex (both produce identical bits) */
 #define HADES252_KERNEL_DEFAULT 0
 #define HADES252_KERNEL_LITERAL 1 /* the reference's round structure, 1972 Montgomery products */
-#define HADES252_KERNEL_FAST 2    /* scale-tracked small-integer MDS formulation */
+#define HADES252_KERNEL_FAST 2    /* scale-tracked small-integer MDS formulation, one state per lane */
+#define HADES252_KERNEL_COOP 3    /* same arithmetic, the five words of a state on five waves: less than half the
+                                     latency, ~2/3 of the throughput; DEFAULT picks it for n_perms <= 16384 */
 
 /* ---- meta --------------------------------------------------------------------------- */
 /* Strategy::rounds() (src/strategies.rs:160-162): TOTAL_FULL_ROUNDS + PARTIAL_ROUNDS = 67 */
@@ -128,13 +130,31 @@ int hades252_fr_op_dev(int op, int impl, const void *d_a, const void *d_b, void 
 int hades252_from_bytes_dev(const void *d_bytes, void *d_limbs, size_t n_scalars, int *d_bad_count, void *stream);
 int hades252_to_bytes_dev(const void *d_limbs, void *d_bytes, size_t n_scalars, void *stream);
 
-/* ---- arity-4 Poseidon Merkle tree (caller shape of dusk-poseidon, README.md:9) ------------ */
-/* parent[i] = perm([tag, child[4i], .., child[4i+3]])[out_idx]; tag in Montgomery limbs.
- * The external convention is tag = 2^4 - 1 = 15, out_idx = 1 (not pinned by the reference). */
+/* ---- Poseidon Merkle trees over the permutation (caller shape of dusk-poseidon, README.md:9) -------
+ * parent = perm([tag, child_0 .. child_{arity-1}, 0 ..])[out_idx]; tag in Montgomery limbs; arity 2 or 4.
+ * The external convention for arity 4 is tag = 2^4 - 1 = 15, out_idx = 1 (NOT pinned by the reference: both
+ * are parameters).  n_leaves must be a power of `arity`, >= arity.  Digests are 32 B Montgomery limbs. */
+int hades252_merkle_level_dev(const void *d_children, void *d_parents, size_t n_parents, int arity,
+                              const uint64_t tag_mont[4], int out_idx, void *stream);
+/* Root only.  d_scratch needs hades252_merkle_scratch_bytes(n_leaves, arity) bytes (0 for a one-level tree;
+ * d_scratch may then be NULL); the root (32 B) is written to d_root.  Large levels run one parent per lane;
+ * the last <= 65 536 nodes (arity 4) run fused inside CUs: 64 parents per workgroup through four levels in LDS. */
+size_t hades252_merkle_scratch_bytes(size_t n_leaves, int arity);
+int hades252_merkle_root_dev(const void *d_leaves, size_t n_leaves, int arity, void *d_scratch, size_t scratch_bytes,
+                             const uint64_t tag_mont[4], int out_idx, void *d_root, void *stream);
+/* Whole tree, every level kept: d_tree (hades252_merkle_tree_bytes = 32 * (n_leaves - 1) / (arity - 1) bytes)
+ * receives level 1 (n/arity digests), then level 2, ... ; the root is its last 32 bytes. */
+size_t hades252_merkle_tree_bytes(size_t n_leaves, int arity);
+int hades252_merkle_build_dev(const void *d_leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
+                              void *d_tree, void *stream);
+/* Openings (authentication paths) from a built tree: for query t with leaf index d_indices[t] (device u64) and
+ * level l = 0 .. depth-1, the arity-1 siblings of the path node, in child order with the node's own position
+ * (index / arity^l) % arity skipped: d_paths[t][l][s], 32 B each, depth * (arity-1) * 32 bytes per query. */
+int hades252_merkle_open_dev(const void *d_leaves, const void *d_tree, size_t n_leaves, int arity,
+                             const uint64_t *d_indices, size_t n_queries, void *d_paths, void *stream);
+/* arity-4 forms (BASELINE config 4) */
 int hades252_merkle4_level_dev(const void *d_children, void *d_parents, size_t n_parents,
                                const uint64_t tag_mont[4], int out_idx, void *stream);
-/* Whole tree, level by level; n_leaves must be a power of 4, >= 4.  d_scratch needs
- * hades252_merkle4_scratch_bytes(n_leaves) bytes; the root (32 B) is written to d_root. */
 size_t hades252_merkle4_scratch_bytes(size_t n_leaves);
 int hades252_merkle4_root_dev(const void *d_leaves, size_t n_leaves, void *d_scratch, size_t scratch_bytes,
                               const uint64_t tag_mont[4], int out_idx, void *d_root, void *stream);

@@ -325,34 +325,41 @@ void hades_oracle_gen_a(uint64_t *out, uint64_t first_elem, size_t n_elems) {
     }
 }
 
-/* ---- arity-4 Merkle level: parent = perm([tag, c0, c1, c2, c3])[out_idx] -------------- */
-typedef struct { const uint64_t *children; uint64_t *parents; const uint64_t *tag; int out_idx; size_t begin, end; } mspan_t;
+/* ---- Merkle level: parent = perm([tag, c_0 .. c_{arity-1}, 0 ..])[out_idx], arity 1..4 (caller shape of
+ * dusk-poseidon, README.md:9; tag / out_idx / arity are PARAMETERS, unpinned by the reference) ---------- */
+typedef struct { const uint64_t *children; uint64_t *parents; const uint64_t *tag; int arity, out_idx; size_t begin, end; } mspan_t;
 static void *merkle_span(void *arg) {
     mspan_t *s = (mspan_t *)arg;
     for (size_t i = s->begin; i < s->end; i++) {
         uint64_t st[20];
+        memset(st, 0, sizeof st);
         memcpy(st, s->tag, 32);
-        memcpy(st + 4, s->children + 16 * i, 128);
+        memcpy(st + 4, s->children + 4 * (size_t)s->arity * i, 32 * (size_t)s->arity);
         hades_oracle_perm(st);
         memcpy(s->parents + 4 * i, st + 4 * s->out_idx, 32);
     }
     return NULL;
 }
-void hades_oracle_merkle4_level(const uint64_t *children, uint64_t *parents, size_t n_parents,
-                                const uint64_t *tag_mont, int out_idx, int n_threads) {
+void hades_oracle_merkle_level(const uint64_t *children, uint64_t *parents, size_t n_parents, int arity,
+                               const uint64_t *tag_mont, int out_idx, int n_threads) {
     hades_oracle_init();
+    if (arity < 1 || arity > 4) return;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
     if ((size_t)n_threads > n_parents) n_threads = n_parents ? (int)n_parents : 1;
     pthread_t th[256];
     mspan_t sp[256];
     for (int t = 0; t < n_threads; t++) {
-        sp[t] = (mspan_t){children, parents, tag_mont, out_idx, n_parents * t / n_threads,
+        sp[t] = (mspan_t){children, parents, tag_mont, arity, out_idx, n_parents * t / n_threads,
                           n_parents * (t + 1) / n_threads};
         if (t) pthread_create(&th[t], NULL, merkle_span, &sp[t]);
     }
     merkle_span(&sp[0]);
     for (int t = 1; t < n_threads; t++) pthread_join(th[t], NULL);
+}
+void hades_oracle_merkle4_level(const uint64_t *children, uint64_t *parents, size_t n_parents,
+                                const uint64_t *tag_mont, int out_idx, int n_threads) {
+    hades_oracle_merkle_level(children, parents, n_parents, 4, tag_mont, out_idx, n_threads);
 }
 
 /* ---- sponge: state = [cap,0,0,0,0]; add 4 scalars to words 1..4, perm; pad_mode 1 appends a single 1

@@ -115,6 +115,36 @@ class Oracle:
                                           ctypes.c_int(threads or self.ncpu))
         return out
 
+    def merkle_level(self, children, arity, tag_mont, out_idx=1, threads=None):
+        ch = np.ascontiguousarray(children, dtype=np.uint64)
+        n = ch.size // (4 * arity)
+        out = np.zeros(n * 4, dtype=np.uint64)
+        tag = np.array(limbs_of(tag_mont), dtype=np.uint64)
+        self.l.hades_oracle_merkle_level(_p(ch), _p(out), ctypes.c_size_t(n), ctypes.c_int(arity), _p(tag),
+                                         ctypes.c_int(out_idx), ctypes.c_int(threads or self.ncpu))
+        return out
+
+    def merkle_tree(self, leaves, arity, tag_mont, out_idx=1):
+        """All levels above the leaves, level 1 first (the layout of hades252_merkle_build_dev), as a list."""
+        levels, cur = [], np.ascontiguousarray(leaves, dtype=np.uint64)
+        while cur.size > 4:
+            cur = self.merkle_level(cur, arity, tag_mont, out_idx)
+            levels.append(cur)
+        return levels
+
+    def merkle_verify_path(self, leaf, index, path, arity, tag_mont, out_idx=1):
+        """Recompute the root from a leaf (4 limbs), its index and its opening path[l][s] (siblings in child
+        order, own position skipped).  Returns the root's 4 limbs."""
+        node = np.ascontiguousarray(leaf, dtype=np.uint64).reshape(4)
+        path = np.ascontiguousarray(path, dtype=np.uint64).reshape(-1, arity - 1, 4)
+        for l in range(path.shape[0]):
+            pos = index % arity
+            sib = list(path[l])
+            children = sib[:pos] + [node] + sib[pos:]
+            node = self.merkle_level(np.concatenate(children), arity, tag_mont, out_idx, threads=1)
+            index //= arity
+        return node
+
     def merkle4_root(self, leaves, tag_mont, out_idx=1):
         level = np.ascontiguousarray(leaves, dtype=np.uint64)
         while level.size > 4:

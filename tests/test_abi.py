@@ -43,6 +43,10 @@ def test_meta_calls_without_gpu(hades_lib):
     assert hades_lib.hades252_perm_batch_dev(None, 4, None) == -1
     assert hades_lib.hades252_merkle4_scratch_bytes(16) == 4 * 32 + 32
     assert hades_lib.hades252_merkle4_scratch_bytes(8) == 0
+    assert hades_lib.hades252_merkle4_scratch_bytes(4) == 0          # one level: no scratch needed
+    assert hades_lib.hades252_merkle_scratch_bytes(8, 2) == 4 * 32 + 2 * 32
+    assert hades_lib.hades252_merkle_tree_bytes(16, 4) == 5 * 32 and hades_lib.hades252_merkle_tree_bytes(8, 2) == 7 * 32
+    assert hades_lib.hades252_merkle_tree_bytes(12, 4) == 0 and hades_lib.hades252_merkle_tree_bytes(16, 3) == 0
 
 
 def test_no_cpu_fallback_in_product():

@@ -106,8 +106,22 @@ def normalised(x):
     return all(0 <= l < (1 << LB) for l in x[:-1]) and abs(val(x)) < (1 << 256)
 
 
-def fast_perm_model(mont_vals):
-    """mont_vals: 5 integers = in-memory BlsScalar values (value * 2^256 mod p).  Returns the same."""
+def finalize_model(x, factor):
+    """finalize(mont_mul_const(x, factor)) of hades_fast.cuh -> fully reduced integer."""
+    v = val(mont_fips(x, D.to_limbs29(factor)))
+    assert -2 * P < v < P
+    v += 2 * P                       # + 2p, then two conditional subtractions
+    assert 0 < v < 3 * P and v < (1 << 256)
+    for _ in range(2):
+        if v >= P:
+            v -= P
+    assert 0 <= v < P
+    return v
+
+
+def fast_perm_model(mont_vals, trace=None):
+    """mont_vals: 5 integers = in-memory BlsScalar values (value * 2^256 mod p).  Returns the same.
+    `trace` (a list) receives the per-round states the way k_perm_trace_fast produces them."""
     sch = D.fast_schedule()
     st = [D.to_limbs29(v) for v in mont_vals]
     for r in range(D.ROUNDS):
@@ -125,6 +139,9 @@ def fast_perm_model(mont_vals):
         st = small_mds(st)
         for x in st:
             assert normalised(x)
+        if trace is not None:
+            trace.append([(finalize_model(x, sch["trace_u"][r]) + sch["trace_d"][r][w] * S.R) % P
+                          for w, x in enumerate(st)])
     f = D.to_limbs29(sch["final_f"])
     out = []
     for x in st:
@@ -150,6 +167,71 @@ def test_model_matches_spec_oracle():
     cases += [[rng.randrange(P) for _ in range(5)] for _ in range(6)]
     for vals in cases:
         got = fast_perm_model([S.to_mont(v) for v in vals])
+        assert got == [S.to_mont(v) for v in S.perm(vals)]
+
+
+def test_trace_model_matches_spec_oracle():
+    """k_perm_trace_fast: un-scaling factor U_r and deferred-constant offset D_r per round."""
+    rng = random.Random(31)
+    for vals in ([1] * 5, [P - 1, 0, 1, P - 2, 2], [rng.randrange(P) for _ in range(5)]):
+        tr, spec_tr = [], []
+        out = fast_perm_model([S.to_mont(v) for v in vals], tr)
+        S.perm(vals, spec_tr)
+        assert len(tr) == 67
+        for r in range(67):
+            assert tr[r] == [S.to_mont(v) for v in spec_tr[r]], r
+        assert tr[66] == out
+
+
+def small_mds_row(i, st):
+    """small_mds_row of hades_coop.cuh: one output row, same arithmetic as row i of small_mds."""
+    acc = sum(st[j][0] * D.MDS_SMALL[i][j] for j in range(5))
+    check_acc(acc)
+    m = acc & MASK
+    acc >>= LB
+    out = [0] * NL
+    for k in range(1, NL):
+        acc += sum(st[j][k] * D.MDS_SMALL[i][j] for j in range(5)) - m * P29[k]
+        assert abs(acc) < (1 << 60)
+        out[k - 1] = acc & MASK
+        acc >>= LB
+    assert -I31 <= acc < I31
+    out[NL - 1] = acc
+    return out
+
+
+def coop_perm_model(mont_vals):
+    """Limb-exact replay of k_perm_coop (hades_coop.cuh): every word on its own wave; partial rounds scale
+    words 0..3 up (G_r) instead of scaling word 4 down."""
+    co = D.coop_schedule()
+    st = [D.to_limbs29(v) for v in mont_vals]
+    for r in range(D.ROUNDS):
+        full = D.is_full_round(r)
+        nxt = []
+        for w in range(5):
+            x = st[w]
+            if full or w == 4:
+                x = [a + b for a, b in zip(x, D.to_balanced29(co["a"][r][w]))]
+                assert all(-LAZY < l < LAZY for l in x)
+                x = sbox(x)
+            else:
+                assert co["a"][r][w] == 0
+                x = mont_fips(x, D.to_limbs29(co["g"][r]))
+            assert normalised(x)
+            nxt.append(x)
+        rows = [small_mds_row(i, nxt) for i in range(5)]
+        assert rows == small_mds(nxt)                 # the row form IS the shipped linear layer
+        st = rows
+    return [finalize_model(x, co["final_f"]) for x in st]
+
+
+def test_coop_model_matches_spec_oracle():
+    rng = random.Random(41)
+    cases = [[1] * 5, [0] * 5, [P - 1] * 5, [15, 1, 2, 3, 4]]
+    cases += [[rng.choice(EDGE) for _ in range(5)] for _ in range(3)]
+    cases += [[rng.randrange(P) for _ in range(5)] for _ in range(4)]
+    for vals in cases:
+        got = coop_perm_model([S.to_mont(v) for v in vals])
         assert got == [S.to_mont(v) for v in S.perm(vals)]
 
 

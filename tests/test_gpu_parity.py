@@ -15,7 +15,7 @@ from oracle_lib import P, R, limbs_of, int_of, digest_ref  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [1, 2]   # HADES252_KERNEL_LITERAL, HADES252_KERNEL_FAST
+KERNELS = [1, 2, 3]   # HADES252_KERNEL_LITERAL, _FAST (one state per lane), _COOP (five waves per state)
 
 
 @pytest.fixture(scope="module")

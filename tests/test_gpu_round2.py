@@ -1,5 +1,6 @@
 """GPU tier, round 2: blob KATs through the device arithmetic, free constant cursor, fast trace,
 variable-length sponge, and BASELINE config 5 at its real size.  Everything goes through the C ABI."""
+import ctypes
 import hashlib
 import os
 import random
@@ -223,6 +224,106 @@ def test_sponge_var_equals_fixed_and_packed(torch_cuda, H, oracle):
     pool = oracle.gen_b(5, int(lens.sum()) + 1)
     got = H.sponge_hash_var(to_dev(torch, pool), to_dev(torch, offs), to_dev(torch, lens), cap, 1)
     assert (to_host(got) == oracle.sponge_var(pool, offs, lens, cap, 1)).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# low-latency kernel (five waves per state) and the dispatch on batch size
+# ---------------------------------------------------------------------------------------------
+def test_coop_kernel_and_default_dispatch(torch_cuda, hades_lib, H, oracle):
+    """HADES252_KERNEL_COOP == HADES252_KERNEL_FAST == oracle on ragged sizes around the block size (64) and the
+    dispatch threshold (2^14), with guard words; DEFAULT must give the same bits on both sides of the threshold."""
+    torch = torch_cuda
+    for n in (1, 5, 63, 64, 65, 127, 128, 129, 1000, (1 << 14) - 1, 1 << 14, (1 << 14) + 1, 40000):
+        inp = oracle.gen_b(7 * n, 5 * n)
+        guard = np.full(40, 0xDEADBEEFCAFEF00D, dtype=np.uint64)
+        exp = oracle.perm_batch(inp)
+        for kernel in (3, 0):
+            buf = to_dev(torch, np.concatenate([guard, inp, guard]))
+            H.ScalarStrategy(kernel).perm(buf[40:40 + 20 * n])
+            got = to_host(buf)
+            assert (got[:40] == guard).all() and (got[-40:] == guard).all(), "wrote outside the batch"
+            assert (got[40:-40] == exp).all(), (n, kernel)
+
+
+def test_coop_kernel_2pow20_vs_fast(torch_cuda, H):
+    torch = torch_cuda
+    a = H.gen_b(5 << 20, "cuda")
+    b = a.clone()
+    H.ScalarStrategy(2).perm(a)
+    H.ScalarStrategy(3).perm(b)
+    assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# Merkle: arity 2 and 4, fused builder, every level, openings
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("arity,depths", [(4, (1, 2, 3, 4, 5, 6, 7, 8, 9)), (2, (1, 2, 3, 6, 7, 8, 13, 14, 15, 16))])
+def test_merkle_roots_and_levels_vs_oracle(torch_cuda, H, oracle, arity, depths):
+    """Roots (root-only path) and EVERY level (build path) vs the oracle, from one-level trees through the
+    single-block, two-launch fused and bulk + fused regimes."""
+    torch = torch_cuda
+    tag = S.to_mont((1 << arity) - 1)
+    for d in depths:
+        n = arity ** d
+        leaves = oracle.gen_b(1000 * d + arity, n)
+        levels = oracle.merkle_tree(leaves, arity, tag, 1)
+        dl = to_dev(torch, leaves).view(-1, 4)
+        root = to_host(H.merkle_root(dl, arity, tag, 1))
+        assert (root == levels[-1]).all(), (arity, d)
+        tree = to_host(H.merkle_build(dl, arity, tag, 1))
+        assert (tree == np.concatenate(levels)).all(), (arity, d)
+    # another output word / tag
+    leaves = oracle.gen_b(5, arity ** 4)
+    got = to_host(H.merkle_root(to_dev(torch, leaves).view(-1, 4), arity, S.to_mont(77), 3))
+    assert (got == oracle.merkle_tree(leaves, arity, S.to_mont(77), 3)[-1]).all()
+
+
+@pytest.mark.parametrize("arity,depth", [(4, 6), (2, 11), (4, 9)])
+def test_merkle_openings(torch_cuda, H, oracle, arity, depth):
+    """Every sibling of every queried path vs the oracle's tree, and each opening re-verified by the oracle:
+    leaf + path -> root."""
+    torch = torch_cuda
+    rng = random.Random(arity * 100 + depth)
+    tag = S.to_mont((1 << arity) - 1)
+    n = arity ** depth
+    leaves = oracle.gen_b(99 + depth, n)
+    dl = to_dev(torch, leaves).view(-1, 4)
+    tree = H.merkle_build(dl, arity, tag, 1)
+    idx = [0, 1, arity - 1, arity, n - 1, n // 2] + [rng.randrange(n) for _ in range(40)]
+    paths = H.merkle_open(dl, tree, arity, to_dev(torch, np.array(idx, dtype=np.uint64)))
+    host = paths.cpu().numpy().view(np.uint64).reshape(len(idx), depth, arity - 1, 4)
+    levels = [leaves.reshape(-1, 4)] + [l.reshape(-1, 4) for l in oracle.merkle_tree(leaves, arity, tag, 1)]
+    root = levels[-1].reshape(4)
+    for t, i in enumerate(idx):
+        node = i
+        for l in range(depth):
+            first, pos = node - node % arity, node % arity
+            sib = [levels[l][first + c] for c in range(arity) if c != pos]
+            assert (host[t, l] == np.array(sib)).all(), (i, l)
+            node //= arity
+        if t < 12:
+            assert (oracle.merkle_verify_path(leaves[4 * i:4 * i + 4], i, host[t], arity, tag, 1) == root).all()
+    with pytest.raises(IndexError):
+        H.merkle_open(dl, tree, arity, to_dev(torch, np.array([n], dtype=np.uint64)))
+
+
+def test_merkle_argument_errors(torch_cuda, H, hades_lib):
+    torch = torch_cuda
+    t = torch.zeros((48, 4), dtype=torch.int64, device="cuda")
+    with pytest.raises(ValueError):
+        H.merkle_root(t, 4, 1)                 # 48 is not a power of 4
+    with pytest.raises(ValueError):
+        H.merkle_root(t[:9], 3, 1)             # arity 3 unsupported
+    tag = (ctypes.c_uint64 * 4)(1, 0, 0, 0)
+    root = torch.zeros(4, dtype=torch.int64, device="cuda")
+    # one-level tree: no scratch needed, NULL accepted (ADVICE r1)
+    assert hades_lib.hades252_merkle4_root_dev(t.data_ptr(), 4, None, 0, tag, 1, root.data_ptr(), None) == 0
+    # scratch too small / missing
+    assert hades_lib.hades252_merkle4_root_dev(t.data_ptr(), 16, None, 0, tag, 1, root.data_ptr(), None) == -5
+    assert hades_lib.hades252_merkle4_root_dev(t.data_ptr(), 16, t.data_ptr(), 32, tag, 1, root.data_ptr(), None) == -5
+    # misaligned root is rejected before anything is enqueued
+    sc = torch.zeros(64, dtype=torch.int64, device="cuda")
+    assert hades_lib.hades252_merkle4_root_dev(t.data_ptr(), 16, sc.data_ptr(), 512, tag, 1, root.data_ptr() + 8, None) == -1
 
 
 # ---------------------------------------------------------------------------------------------
