@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_merkle_level_fast(const uint8_t *
 // In-place permutation of up to 64 states per 320-thread block.
 __global__ void __launch_bounds__(kCoopThreads) k_perm_coop(uint8_t *states, size_t n) {
     __shared__ CoopLds L;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = coop_word_of_wave(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));   // the word this wave owns
     const int lane = threadIdx.x & (kWave - 1);
     const size_t rec0 = (size_t)blockIdx.x * kCoopStates;
     const size_t total = n * 10, chunk0 = rec0 * 10;
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(kCoopThreads) k_merkle_coop(const uint8_t *__r
                                                              uint8_t *__restrict__ out_last, size_t n_parents, Fr tag,
                                                              int out_idx, int n_levels) {
     __shared__ CoopLds L;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = coop_word_of_wave(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));   // the word this wave owns
     const int lane = threadIdx.x & (kWave - 1);
     const size_t par0 = (size_t)blockIdx.x * kCoopStates;
     int valid = (int)(n_parents - par0 < (size_t)kCoopStates ? n_parents - par0 : (size_t)kCoopStates);
@@ -692,9 +692,16 @@ struct HostSlot {
     hipStream_t stream = nullptr;
     void *buf = nullptr;
     size_t cap = 0;
+    void *pinned = nullptr;       // small-call staging: page-locked host memory the kernels access directly
+    void *pinned_dev = nullptr;   // ... and its device-side address
 };
+// Calls of at most this many states skip both DMA copies: the states are copied (by the CPU) into a
+// page-locked buffer that the kernel reads and writes over PCIe itself -- one launch + one synchronisation.
+static constexpr size_t kPinnedStates = 256;
 static std::mutex g_pool_mu;
 static std::vector<HostSlot> g_pool;
+
+static void release_slot(const HostSlot &s);
 
 static int acquire_slot(size_t bytes, HostSlot &out) {
     int dev = 0;
@@ -716,6 +723,16 @@ static int acquire_slot(size_t bytes, HostSlot &out) {
     if (s.device < 0) {
         s.device = dev;
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    }
+    if (bytes == 0 && s.pinned == nullptr) {           // small-call slot: page-locked staging instead
+        hipError_t e = hipHostMalloc(&s.pinned, kPinnedStates * 160, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&s.pinned_dev, s.pinned, 0);
+        if (e != hipSuccess) {
+            tl_last_hip_error = (int)e;
+            (void)hipGetLastError();
+            release_slot(s);
+            return HADES252_ERR_HIP;
+        }
     }
     if (s.cap < bytes) {
         if (s.buf) (void)hipFree(s.buf);
@@ -741,11 +758,36 @@ static void release_slot(const HostSlot &s) {
 
 // Host batch on the current device: chunked, double-buffered H2D / kernel / D2H on two streams.
 // `bytes_format` inputs have already been validated (all < p).
-static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, bool bytes_format) {
+static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, bool bytes_format,
+                                             bool already_registered = false) {
     if (n_perms == 0) return HADES252_OK;
     if (states == nullptr) return HADES252_ERR_INVALID_ARG;
     int rc = check_device();
     if (rc != HADES252_OK) return rc;
+    if (n_perms <= kPinnedStates) {
+        HostSlot sl;
+        rc = acquire_slot(0, sl);
+        if (rc != HADES252_OK) return rc;
+        memcpy(sl.pinned, states, n_perms * 160);
+        void *d = sl.pinned_dev;
+        if (bytes_format) {
+            rc = hades252_from_bytes_dev(d, d, n_perms * 5, nullptr, sl.stream);
+            if (rc == HADES252_OK) rc = hades252_perm_batch_dev(d, n_perms, sl.stream);
+            if (rc == HADES252_OK) rc = hades252_to_bytes_dev(d, d, n_perms * 5, sl.stream);
+        } else {
+            rc = hades252_perm_batch_dev(d, n_perms, sl.stream);
+        }
+        hipError_t e = hipStreamSynchronize(sl.stream);
+        if (rc == HADES252_OK && e == hipSuccess) memcpy(states, sl.pinned, n_perms * 160);
+        release_slot(sl);                                   // only now: the staging buffer belongs to the slot
+        if (rc != HADES252_OK) return rc;
+        if (e != hipSuccess) {
+            tl_last_hip_error = (int)e;
+            (void)hipGetLastError();
+            return HADES252_ERR_HIP;
+        }
+        return HADES252_OK;
+    }
     const size_t kChunk = (size_t)1 << 18;                // 40 MiB of states per chunk
     const size_t chunk = n_perms < kChunk ? n_perms : kChunk;
     const int nbuf = n_perms > chunk ? 2 : 1;
@@ -774,7 +816,7 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
         const char *e = getenv("HADES252_HOST_PIN");
         return !(e && e[0] == '0');
     }();
-    if (pin_enabled && n_perms * 160 >= ((size_t)8 << 20)) {
+    if (pin_enabled && !already_registered && n_perms * 160 >= ((size_t)8 << 20)) {
         if (hipHostRegister(h, n_perms * 160, hipHostRegisterDefault) == hipSuccess)
             registered = true;
         else
@@ -849,6 +891,18 @@ int hades252_perm_batch_multi(uint64_t *states, size_t n_perms, int n_devices) {
     if (n_devices <= 0) n_devices = avail;
     if (n_devices > avail) return HADES252_ERR_INVALID_ARG;
     if ((size_t)n_devices > n_perms) n_devices = (int)n_perms;
+    // Page-lock the caller's buffer ONCE for all devices (shards share boundary pages: per-shard registration
+    // would overlap and be refused for some shards, by a race); portable = visible to every device.
+    bool registered = false;
+    {
+        const char *e = getenv("HADES252_HOST_PIN");
+        if (!(e && e[0] == '0') && n_perms * 160 >= ((size_t)8 << 20)) {
+            if (hipHostRegister(states, n_perms * 160, hipHostRegisterPortable) == hipSuccess)
+                registered = true;
+            else
+                (void)hipGetLastError();
+        }
+    }
     std::vector<int> rcs(n_devices, HADES252_OK);
     std::vector<int> hip_errs(n_devices, 0);
     std::vector<std::thread> threads;
@@ -861,11 +915,14 @@ int hades252_perm_batch_multi(uint64_t *states, size_t n_perms, int n_devices) {
                 hip_errs[g] = (int)err;
                 return;
             }
-            rcs[g] = perm_batch_host_on_current_device(states + 20 * b, e - b, false);
+            // registered: skip the per-shard attempt; not registered (refused / disabled): also skip it -- a
+            // sub-range attempt would only repeat the refusal -- and use the pageable path
+            rcs[g] = perm_batch_host_on_current_device(states + 20 * b, e - b, false, true);
             hip_errs[g] = tl_last_hip_error;
         });
     }
     for (auto &t : threads) t.join();
+    if (registered) (void)hipHostUnregister(states);
     for (int g = 0; g < n_devices; g++)
         if (rcs[g] != HADES252_OK) {
             tl_last_hip_error = hip_errs[g];

@@ -26,6 +26,15 @@ constexpr int kCoopWaves = 5;
 constexpr int kCoopThreads = kCoopWaves * kWave;   // 320
 constexpr int kCoopStates = kWave;                 // states per block
 
+// Which word a wave owns.  The five waves of a block land on the CU's four SIMDs round-robin (wave i on SIMD
+// i % 4: tools/ubench3.hip "coop" section records HW_ID), so waves 0 and 4 share a SIMD.  Word 4 -- the only
+// S-box of a partial round, the critical path -- must have a SIMD to itself; the sharing pair gets two of the
+// cheap words (one constant product each in a partial round).  If the hardware placed waves differently the
+// kernel would only be slower, never wrong.
+__device__ __forceinline__ int coop_word_of_wave(int wave) {
+    return wave == 1 ? 4 : (wave == 4 ? 1 : wave);      // waves 0,1,2,3,4 -> words 0,4,2,3,1
+}
+
 struct CoopTables {
     int32_t round[67][64];    // per round {A[5][9] (balanced limbs), G[9], pad}
     int32_t final_f[kNL + 7];

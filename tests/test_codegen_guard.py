@@ -1,0 +1,76 @@
+"""CPU tier: regression guard on the code hipcc generates for the hot kernels (no GPU needed).
+
+The shipped kernel's speed rests on two compiler-facing tricks in hades_fast.cuh (`pin`, `limb_fence`): with
+them every limb product is ONE `v_mad_i64_i32`; without them LLVM widens limbs to 64 bits (two multiply-adds
+and two moves per product) or re-associates column sums (an extra 64-bit add per column).  A ROCm bump could
+silently undo either.  This test compiles the device code to assembly for gfx950 and asserts, per kernel:
+  k_perm_fast      v_mad_i64_i32 within +-2 % of 2898, no v_mad_u64_u32 beyond the staging/finalize few,
+                   0 scratch, <= 96 VGPRs (=> 5 waves/SIMD by registers)
+  every hot kernel 0 scratch (sponge, Merkle, trace, cooperative, per-lane level) -- round 1's sponge spilled
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "hades252_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("asm") / "hades252.s"
+    r = subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-gpu-rdc", "--cuda-device-only", "-S",
+                        "-o", str(out), "hades252.hip", "-Rpass-analysis=kernel-resource-usage"],
+                       cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    text = open(out).read()
+    # kernel bodies: from "<name>:" to its s_endpgm
+    bodies = {}
+    for m in re.finditer(r"^(_Z\w+):\s*; @\1\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
+        bodies[m.group(1)] = m.group(2)
+    # resource remarks
+    res, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = res.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/lane\]| \[waves/SIMD\]| \[bytes/block\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return bodies, res
+
+
+def find(d, needle):
+    hits = [k for k in d if needle in k]
+    assert len(hits) >= 1, "kernel %s not found in %s" % (needle, sorted(d)[:50])
+    return hits
+
+
+def test_perm_fast_instruction_mix(device_asm):
+    bodies, res = device_asm
+    (name,) = find(bodies, "k_perm_fast")
+    body = bodies[name]
+    mads = len(re.findall(r"\bv_mad_i64_i32\b", body))
+    umads = len(re.findall(r"\bv_mad_u64_u32\b", body))
+    assert abs(mads - 2898) <= 0.02 * 2898, "one multiply-add per limb product no longer holds: %d v_mad_i64_i32" % mads
+    assert umads <= 300, "%d v_mad_u64_u32: limbs are being widened to 64 bits?" % umads
+    total = len([l for l in body.splitlines() if re.match(r"\s+[vs]_", l)])
+    assert total < 5600, "kernel grew to %d instructions (I-cache: 64 KB ~ 8 k instructions of 8 B)" % total
+    r = res[name]
+    assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0
+    assert r["VGPRs"] <= 96, r
+
+
+@pytest.mark.parametrize("needle", ["k_perm_fast", "k_sponge", "k_merkle_level_fast", "k_merkle_coop", "k_perm_coop",
+                                    "k_perm_trace_fast", "k_fr_op"])
+def test_hot_kernels_have_no_scratch(device_asm, needle):
+    _, res = device_asm
+    for name in find(res, needle):
+        assert res[name]["ScratchSize"] == 0, (name, res[name])
+        assert res[name]["VGPRs Spill"] == 0, (name, res[name])      # (SGPR spills go to VGPR lanes, not memory)

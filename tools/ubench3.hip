@@ -132,6 +132,13 @@ __global__ void __launch_bounds__(BLOCK) k_blocks(uint32_t *out, Stamp *stamps, 
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// ---- 4. where do the five waves of a 320-thread block land? ----------------------------------------------------
+__global__ void __launch_bounds__(320) k_where(Stamp *st) {
+    Stamp s;
+    stamp_begin(s);
+    stamp_end(s, st, blockIdx.x * 5 + threadIdx.x / 64);
+}
+
 typedef void (*kern_t)(uint32_t *, Stamp *, int, uint32_t);
 
 struct Result { double wall_ms, rate_wall_g, rate_wave_g, cyc_per_op_wall, cyc_per_op_wave; };
@@ -237,6 +244,18 @@ int main(int argc, char **argv) {
         run("lone sbox", k_blocks<2, 64>, 1, 64, 0, IB, 1, 1);
         run("lone small_mds", k_blocks<3, 64>, 1, 64, 0, IB, 1, 1);
         run("lone partial round", k_blocks<5, 64>, 1, 64, 0, IB, 1, 1);
+    }
+    if (all || !strcmp(what, "coop")) {
+        printf("== 4. SIMD of each wave of a 320-thread block (HW_ID bits 5:4), 8 blocks ==\n");
+        hipLaunchKernelGGL(k_where, dim3(8), dim3(320), 0, 0, d_st);
+        CHECK(hipDeviceSynchronize());
+        std::vector<Stamp> s(40);
+        CHECK(hipMemcpy(s.data(), d_st, 40 * sizeof(Stamp), hipMemcpyDeviceToHost));
+        for (int b = 0; b < 8; b++) {
+            printf("block %d: xcc %u cu %2u  wave->simd:", b, s[b * 5].xcc_id & 0xf, (s[b * 5].hw_id >> 8) & 0xf);
+            for (int w = 0; w < 5; w++) printf(" %u", (s[b * 5 + w].hw_id >> 4) & 3);
+            printf("\n");
+        }
     }
     if (all || !strcmp(what, "blocks")) {
         printf("== 3. building blocks under forced residency (ops = block executions per wave) ==\n");
