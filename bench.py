@@ -39,19 +39,20 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_PERM = 320
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak, MI355X_MICROARCH.md
-# The binding resource is VALU issue.  Static per-permutation instruction counts of k_perm_fast
-# (rocprofv3 SQ_INSTS_VALU / SQ_WAVES agrees) and the chip-wide sustained
-# v_mad_u64_u32 issue rate measured by tools/ubench2.hip (profiles/ubench2_*.txt).
-MADS_PER_PERM = 99 * 387 + 64 * 153 + 67 * 265
-VALU_PEAK_G_WAVE_INSTR = 545.0
-# Issue-cycle model: 64-bit-class VALU ops (multiply-adds, 64-bit shifts) occupy a SIMD for 4 cycles
-# per wave-instruction, 32-bit ops for 2 (MI355X_MICROARCH.md: SIMD-32 issues wave64 in 2 cycles; the
-# 64-bit integer ops run at half that rate, tools/ubench*.hip).  Counts per permutation from the ISA
-# of k_perm_fast / rocprofv3 SQ_INSTS_VALU = 88.7 k.
-OPS64_PER_PERM = MADS_PER_PERM + 9400
-OPS32_PER_PERM = 88700 - OPS64_PER_PERM
-PEAK_CLOCK_HZ = 2.4e9
+# The binding resource is VALU issue.  Per-permutation instruction counts of k_perm_fast: static ISA count
+#  = rocprofv3 SQ_INSTS_VALU / SQ_WAVES = 88 702 per wave (profiles/r2/pmc_summary.json).
+MADS_PER_PERM = 99 * 387 + 64 * 153 + 67 * 265      # 64-bit multiply-adds
+OPS64_PER_PERM = MADS_PER_PERM + 9400               # + 64-bit shifts: same issue class
+OPS32_PER_PERM = 88700 - OPS64_PER_PERM             # 32-bit ops
 N_SIMD = 1024
+PEAK_CLOCK_HZ = 2.4e9
+# Issue model: a wave64 instruction occupies its SIMD-16 for 4 cycles when 64-bit, 2 cycles when 32-bit
+# (MI355X_MICROARCH.md).  IDEAL peak = one 64-bit op per SIMD per 4 cycles at the 2.4 GHz peak clock.
+VALU_IDEAL_G_WI = N_SIMD * PEAK_CLOCK_HZ / 4 / 1e9  # 614.4 G 64-bit wave-instr/s
+# MEASURED peak: tools/ubench3.hip, pure v_mad_i64_i32 (v,s operands) stream, 8 waves/SIMD forced by an LDS pad,
+# residency verified from HW_ID, wall-clock rate == in-kernel-timestamp rate (profiles/r2/ubench3_valu_ceiling.txt:
+# 546.96 / 547.02 G wave-instr/s); = 4.4 cycles per instruction at the 2.36 GHz the counters show under this load.
+VALU_MEASURED_G_WI = 547.0
 
 
 def usable_cores() -> int:
@@ -227,10 +228,10 @@ def main():
     if os.path.exists(tpath):
         try:
             rec = json.load(open(tpath))
-            if rec.get("perms_per_launch") == n and rec.get("kernel_source_hash") == build.source_hash():
+            if rec.get("perms_per_launch") == n and rec.get("kernel_source_hash") == build.perm_fast_hash():
                 traffic = rec.get("hbm_bytes_per_launch")
                 traffic_source = ("NOT measured in this run: replayed from the committed rocprofv3 PMC passes "
-                                  "(profiles/hbm_traffic.json, same kernel source hash %s)" % build.source_hash()[:12])
+                                  "(profiles/hbm_traffic.json, same kernel source hash %s)" % build.perm_fast_hash()[:12])
         except Exception:
             traffic = None
     pow2 = n & (n - 1) == 0
@@ -254,15 +255,17 @@ def main():
                      "kernel_ms": kernel_ms_max, "algorithmic_bytes_per_perm": ALGO_BYTES_PER_PERM,
                      "note": "HBM traffic equals the algorithmic bytes; the kernel is VALU-issue bound "
                              "(~89 k instructions per 320 B), see valu_issue and DESIGN.md"},
-        "valu_issue": {"bound": "v_mad_u64_u32 issue", "mads_per_perm": MADS_PER_PERM,
-                       "achieved": MADS_PER_PERM * n / (kernel_ms_max * 1e-3) / 64 / 1e9,
-                       "peak": VALU_PEAK_G_WAVE_INSTR, "unit": "G wave-instr/s",
-                       "frac": MADS_PER_PERM * n / (kernel_ms_max * 1e-3) / 64 / 1e9 / VALU_PEAK_G_WAVE_INSTR,
-                       "issue_cycle_frac": (OPS64_PER_PERM * 4 + OPS32_PER_PERM * 2) * (n / 64.0) / N_SIMD
-                                           / (kernel_ms_max * 1e-3 * PEAK_CLOCK_HZ),
-                       "note": "64-bit multiply-adds only (87% of the 64-bit-class VALU work); the binding bound. "
-                               "issue_cycle_frac = modelled VALU issue cycles (4 per 64-bit op, 2 per 32-bit op) / "
-                               "(kernel time x 2.4 GHz peak clock)"},
+        "valu_issue": (lambda eq: {
+            "bound": "VALU issue: 64-bit integer multiply-add pipe (the binding bound; HBM idles at 1.7 %)",
+            "achieved": eq, "unit": "G 64-bit-equivalent wave-instr/s",
+            "peak": VALU_IDEAL_G_WI, "frac": eq / VALU_IDEAL_G_WI,
+            "peak_measured": VALU_MEASURED_G_WI, "frac_of_measured": eq / VALU_MEASURED_G_WI,
+            "mads_per_perm": MADS_PER_PERM, "ops64_per_perm": OPS64_PER_PERM, "ops32_per_perm": OPS32_PER_PERM,
+            "note": "achieved = (64-bit ops + 0.5 x 32-bit ops) per permutation x permutations/s / 64 lanes; peak = 1024 "
+                    "SIMDs x 2.4 GHz / 4 cycles (ideal pipe); peak_measured = sustained pure v_mad_i64_i32 stream at 8 "
+                    "waves/SIMD (tools/ubench3.hip, profiles/r2/): the kernel runs at the rate the pipe sustains, "
+                    "only fewer instructions can make it faster"})(
+            (OPS64_PER_PERM + 0.5 * OPS32_PER_PERM) * n / (kernel_ms_max * 1e-3) / 64 / 1e9),
         "digest": ["%016x" % d for d in digest],
     }
     if world > 1:

@@ -22,8 +22,10 @@ LIB = os.path.join(CSRC, "libhades252.so")
 STAMP = LIB + ".stamp"
 LOCK = LIB + ".lock"
 SOURCES = ["hades252.hip"]
-DEPS = ["hades252.hip", "fr32.cuh", "staging.cuh", "hades_literal.cuh", "hades_fast.cuh",
+DEPS = ["hades252.hip", "fr32.cuh", "staging.cuh", "hades_literal.cuh", "hades_fast.cuh", "hades_coop.cuh",
         "hades_constants.inc", os.path.join("..", "..", "include", "hades252.h")]
+# what the dominant kernel (k_perm_fast) is made of: profiles recorded for it stay valid while these are unchanged
+PERM_FAST_DEPS = ["fr32.cuh", "staging.cuh", "hades_fast.cuh", "hades_constants.inc"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-pthread",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
@@ -32,6 +34,15 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-pth
 def source_hash() -> str:
     h = hashlib.sha256(" ".join(FLAGS).encode())
     for d in DEPS:
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(d.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def perm_fast_hash() -> str:
+    """Hash of the sources + flags that determine k_perm_fast (keys committed PMC profiles to the kernel)."""
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in PERM_FAST_DEPS:
         with open(os.path.join(CSRC, d), "rb") as f:
             h.update(d.encode() + b"\0" + f.read())
     return h.hexdigest()

@@ -15,3 +15,27 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 benc
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_sq -- python3 bench.py $ARGS > $OUT/bench_sq.json 2> $OUT/pmc_sq.log
 python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# the VALU ceiling microbenchmark under the same counters (program directly after --)
+if [ -x build_tools/ubench3 ]; then
+  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_ubench -- ./build_tools/ubench3 rates > $OUT/ubench3_rates_under_pmc.txt 2> $OUT/pmc_ubench.log
+  python3 - "$OUT" <<'PY' > $OUT/ubench3_pmc_summary.txt 2>&1
+import csv, glob, os, sys
+out = sys.argv[1]
+rows = {}
+order = []
+for f in sorted(glob.glob(os.path.join(out, "pmc_ubench", "**", "*counter_collection.csv"), recursive=True)):
+    for r in csv.DictReader(open(f)):
+        key = (r.get("Dispatch_Id"), r.get("Kernel_Name", "")[:40], r.get("Grid_Size"))
+        if key not in rows:
+            rows[key] = {}
+            order.append(key)
+        rows[key][r["Counter_Name"]] = rows[key].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+print("dispatch kernel grid | SQ_WAVES SQ_INSTS_VALU instr/wave SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU  (ubench3 rates, in launch order)")
+for k in order:
+    c = rows[k]
+    w = c.get("SQ_WAVES", 0)
+    print("%6s %-40s %8s | %8.0f %14.0f %10.1f %14.0f %14.0f" % (k[0], k[1], k[2], w, c.get("SQ_INSTS_VALU", 0),
+          c.get("SQ_INSTS_VALU", 0) / w if w else 0, c.get("SQ_BUSY_CYCLES", 0), c.get("SQ_ACTIVE_INST_VALU", 0)))
+PY
+  cat $OUT/ubench3_pmc_summary.txt | head -60
+fi

@@ -72,6 +72,30 @@ for k, cs in summary.items():
         summary[k]["hbm_write_bytes"] = wr
         summary[k]["hbm_bytes_per_launch"] = rd + wr
 json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+# bench.py replays the per-launch HBM traffic of k_perm_fast from profiles/hbm_traffic.json -- only when the
+# kernel source hash recorded here matches the library it runs
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    from hades252_amd import build as _hb
+    for k, cs in summary.items():
+        if "k_perm_fast" in k and "hbm_bytes_per_launch" in cs:
+            perms = None
+            try:
+                perms = json.loads(open(os.path.join(out, "bench_fetch.json")).read().strip().splitlines()[-1])["config"]["perms_per_gpu"]
+            except Exception:
+                pass
+            rec = {"kernel": "k_perm_fast", "perms_per_launch": perms, "kernel_source_hash": _hb.perm_fast_hash(),
+                   "hbm_bytes_per_launch": cs["hbm_bytes_per_launch"], "hbm_read_bytes": cs["hbm_read_bytes"],
+                   "hbm_write_bytes": cs["hbm_write_bytes"],
+                   "valu_instructions_per_wave": (cs.get("SQ_INSTS_VALU", 0) / cs["SQ_WAVES"]) if cs.get("SQ_WAVES") else None,
+                   "algorithmic_bytes_per_launch": 320 * perms if perms else None,
+                   "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes around `python3 bench.py "
+                             "--steps 5 --warmup 1 --no-cpu-baseline` (tools/profile_round.sh); bytes = counter*1024, "
+                             "FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section)"}
+            json.dump(rec, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
+            print("\nwrote hbm_traffic.json:", rec)
+except Exception as e:                     # pragma: no cover
+    print("hbm_traffic.json not written:", e)
 for f in ("bench_trace.json", "bench_fetch.json"):
     p = os.path.join(out, f)
     if os.path.exists(p):
