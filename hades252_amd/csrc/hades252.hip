@@ -259,6 +259,7 @@ __global__ void __launch_bounds__(kCoopThreads) k_perm_coop(uint8_t *states, siz
     const size_t rec0 = (size_t)blockIdx.x * kCoopStates;
     const size_t total = n * 10, chunk0 = rec0 * 10;
     uint4 *g = reinterpret_cast<uint4 *>(states + rec0 * 160);
+    coop_load_constants(&d_coop, L);
 #pragma unroll
     for (int c = threadIdx.x; c < kCoopStates * 10; c += kCoopThreads) {
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -307,6 +308,7 @@ __global__ void __launch_bounds__(kCoopThreads) k_merkle_coop(const uint8_t *__r
     const int lane = threadIdx.x & (kWave - 1);
     const size_t par0 = (size_t)blockIdx.x * kCoopStates;
     int valid = (int)(n_parents - par0 < (size_t)kCoopStates ? n_parents - par0 : (size_t)kCoopStates);
+    coop_load_constants(&d_coop, L);
     // children of this block: valid * ARITY digests, contiguous -> stage[child index * 32]
     {
         const uint4 *g = reinterpret_cast<const uint4 *>(children + par0 * ARITY * 32);

@@ -15,6 +15,27 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 benc
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_sq -- python3 bench.py $ARGS > $OUT/bench_sq.json 2> $OUT/pmc_sq.log
 python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# wire-format kernels beyond the Infinity Cache, with HBM byte counters
+python3 tools/wire_bw.py > $OUT/wire_bw.txt 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_wire_fetch -- python3 tools/wire_bw.py > /dev/null 2> $OUT/pmc_wire_fetch.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_wire_write -- python3 tools/wire_bw.py > /dev/null 2> $OUT/pmc_wire_write.log
+python3 - "$OUT" <<'PY' >> $OUT/wire_bw.txt 2>&1
+import csv, glob, os, sys
+out = sys.argv[1]
+acc = {}
+for d in ("pmc_wire_fetch", "pmc_wire_write"):
+    for f in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r.get("Kernel_Name", "")
+            if "bytes" in k:
+                acc.setdefault((k.split("(")[0], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+for (k, c), v in sorted(acc.items()):
+    avg = sum(v) / len(v)
+    b = avg * 1024 * (2 if c == "FETCH_SIZE" else 1)
+    print("%-14s %-10s n=%d  avg counter %.6g  -> %.4g bytes per launch%s (algorithmic: 2.147e9)"
+          % (k, c, len(v), avg, b, " (x2 gfx950 wide-read correction)" if c == "FETCH_SIZE" else ""))
+PY
+cat $OUT/wire_bw.txt
 # the VALU ceiling microbenchmark under the same counters (program directly after --)
 if [ -x build_tools/ubench3 ]; then
   rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_ubench -- ./build_tools/ubench3 rates > $OUT/ubench3_rates_under_pmc.txt 2> $OUT/pmc_ubench.log
