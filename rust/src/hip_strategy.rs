@@ -35,6 +35,11 @@ extern "C" {
 pub struct HipStrategy {
     /// 0 = current device only; n > 0 = shard host batches over the first n GPUs.
     pub devices: i32,
+    /// Batches of fewer permutations than this stay on the reference's own `ScalarStrategy`
+    /// (0 = always use the GPU).  Measured on MI355X: one GPU call costs ~121 us whatever the batch
+    /// size up to 16384 states, one CPU permutation ~30-60 us; 3 is the break-even for a
+    /// single-threaded caller.  (libhades252 itself has no CPU path.)
+    pub cpu_below: usize,
 }
 
 impl HipStrategy {
@@ -86,6 +91,12 @@ impl Strategy<BlsScalar> for HipStrategy {
             "Hades252 state length must be a multiple of WIDTH"
         );
         let n_perms = data.len() / WIDTH;
+        if n_perms < self.cpu_below {
+            for chunk in data.chunks_mut(WIDTH) {
+                ScalarStrategy::new().perm(chunk);
+            }
+            return;
+        }
         let ptr = data.as_mut_ptr() as *mut u64;
         let rc = unsafe {
             if self.devices > 0 {
