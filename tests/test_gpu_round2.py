@@ -257,10 +257,11 @@ def test_coop_kernel_2pow20_vs_fast(torch_cuda, H):
 # ---------------------------------------------------------------------------------------------
 # Merkle: arity 2 and 4, fused builder, every level, openings
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("arity,depths", [(4, (1, 2, 3, 4, 5, 6, 7, 8, 9)), (2, (1, 2, 3, 6, 7, 8, 13, 14, 15, 16))])
+@pytest.mark.parametrize("arity,depths", [(4, (1, 2, 3, 4, 5, 6, 7, 8, 9, 10)), (2, (1, 2, 3, 6, 7, 8, 13, 14, 15, 16, 17))])
 def test_merkle_roots_and_levels_vs_oracle(torch_cuda, H, oracle, arity, depths):
     """Roots (root-only path) and EVERY level (build path) vs the oracle, from one-level trees through the
-    single-block, two-launch fused and bulk + fused regimes."""
+    single-block, two-launch fused, bulk + fused and two-levels-per-launch bulk regimes (the last at 4^10 / 2^17
+    leaves)."""
     torch = torch_cuda
     tag = S.to_mont((1 << arity) - 1)
     for d in depths:
