@@ -37,6 +37,8 @@ SIGNATURES = {
     "hades252_perm_batch_multi": (c_int, [c_void_p, c_size_t, c_int]),
     "hades252_perm_trace_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "hades252_perm_trace_dev_ex": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
+    "hades252_witness_wires": (c_int, []),
+    "hades252_perm_witness_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "hades252_add_round_key_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
     "hades252_add_round_key_at_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
     "hades252_apply_full_round_at_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),

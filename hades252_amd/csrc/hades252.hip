@@ -37,6 +37,12 @@ __device__ const CoopTables d_coop = {HADES_COOP_ROUND_INIT, HADES_COOP_FINAL_F,
 __device__ const int32_t d_trace_u[67][16] = HADES_FAST_TRACE_U_INIT;
 // ... + D_r: the partial-round constants of words 0..3 that the shipped schedule defers (hades_fast.cuh item 5)
 __device__ const uint32_t d_trace_d[67][5][8] = HADES_FAST_TRACE_D_INIT;
+// witness kernel: un-scaling factors {u_in,u2,u4,u5,w1,u_post} and additive corrections {d1[5], d2[5]} per round
+struct WitnessTables {
+    int32_t u[67][64];
+    uint32_t d[67][10][8];
+};
+__device__ const WitnessTables d_wit = {HADES_WITNESS_U_INIT, HADES_WITNESS_D_INIT};
 // generic radix-2^29 field ops (hades252_fr_op_dev)
 __device__ const int32_t d_rp_mod_p[16] = HADES_RP_MOD_P29;
 __device__ const int32_t d_rp2_over_r[16] = HADES_RP2_OVER_R29;
@@ -119,6 +125,126 @@ __global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__
             slab_put<5>(slab, w, v);
         }
         slab_flush<5>(trace + (size_t)r * n * 160, rec0, n, slab);
+    }
+}
+
+// Full gadget witness: EVERY gate output of the reference's GadgetStrategy for every state -- the 972 values a
+// PLONK prover assigns per permutation (src/strategies/gadget.rs:41-133: round-0 key additions, v^2 / v^4 / v^5 of
+// each S-box, and per linear layer the 3-term partial sums r1[j] and the rows r2[j] with the NEXT round's constant
+// appended).  Wire-major output: wires[g] is a batch of n scalars (32 B, in-memory BlsScalar), g in gate order.
+// The rounds are those of k_perm_fast; each value is un-scaled with one constant product, fully reduced and, where
+// the shipped schedule defers constants, corrected by a known offset (hades252_amd/_derive.py::witness_schedule;
+// limb-exact replay: tests/test_fast_model.py::witness_model).  Loops over words rotate the state so that every
+// piece of code exists once (I-cache).
+__device__ __forceinline__ void store_wire(uint8_t *wires, size_t n, int wire, size_t rec, bool live, const Fr &v) {
+    if (live) {
+        uint4 *q = reinterpret_cast<uint4 *>(wires + ((size_t)wire * n + rec) * 32);
+        q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+        q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    }
+}
+__device__ __forceinline__ void rotate_right(F29 (&st)[5]) {
+    const F29 t = st[4];
+    st[4] = st[3];
+    st[3] = st[2];
+    st[2] = st[1];
+    st[1] = st[0];
+    st[0] = t;
+}
+
+__global__ void __launch_bounds__(kBlock, 3) k_perm_witness(const uint8_t *__restrict__ states,
+                                                            uint8_t *__restrict__ wires, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<5>(lds);
+    const size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    const size_t rec = rec0 + (threadIdx.x & (kWave - 1));
+    const bool live = rec < n;
+    F29 st[5];
+    {
+        Fr in[5];
+        wave_load_records<5>(states, rec0, n, slab, in);
+#pragma unroll
+        for (int w = 0; w < 5; w++) st[w] = to_f29(in[w]);
+    }
+    int wire = 0;
+#pragma unroll 1
+    for (int r = 0; r < 67; r++) {
+        const int32_t *rc = d_fast.round[r];
+        const int32_t *u = d_wit.u[r];
+        const bool full = r < 4 || r >= 63;
+        if (full) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) add_lazy(st[w], rc + w * kNL);
+        }
+        add_lazy(st[4], rc + 4 * kNL);
+        if (r == 0) {
+#pragma unroll 1
+            for (int i = 0; i < 5; i++) {               // state after the first round key: word 4 - i sits at st[4]
+                store_wire(wires, n, wire + 4 - i, rec, live, finalize(mont_mul_const(st[4], u)));
+                rotate_right(st);
+            }
+            wire += 5;
+        }
+        // S-boxes: v^2, v^4, v^5 (partial round: word 4 only, then the K_r product that re-scales it)
+        const int cnt = full ? 5 : 1;
+#pragma unroll 1
+        for (int i = 0; i < cnt; i++) {
+            const int w = full ? 4 - i : 0;             // gate order: word 0 first (a partial round has one S-box)
+            const F29 v2 = mont_sqr(st[4]);
+            store_wire(wires, n, wire + 3 * w, rec, live, finalize(mont_mul_const(v2, u + kNL)));
+            const F29 v4 = mont_sqr(v2);
+            store_wire(wires, n, wire + 3 * w + 1, rec, live, finalize(mont_mul_const(v4, u + 2 * kNL)));
+            F29 v5 = mont_mul(v4, st[4]);
+            if (!full) v5 = mont_mul_const(v5, rc + 5 * kNL);
+            store_wire(wires, n, wire + 3 * w + 2, rec, live, finalize(mont_mul_const(v5, u + 3 * kNL)));
+            st[4] = v5;
+            if (full) rotate_right(st);
+#pragma unroll
+            for (int k = 0; k < kNL; k++) limb_fence(st[4].l[k]);
+        }
+        wire += 3 * cnt;
+        // r1[j] = M[j][0] z0 + M[j][1] z1 + M[j][2] z2: three columns of the small-integer layer, one-limb step
+#pragma unroll 1
+        for (int j = 0; j < 5; j++) {
+            const int32_t c0 = d_coop.mds[j][0], c1 = d_coop.mds[j][1], c2 = d_coop.mds[j][2];
+            F29 y;
+            int64_t acc = 0;
+            mac(acc, st[0].l[0], c0);
+            mac(acc, st[1].l[0], c1);
+            mac(acc, st[2].l[0], c2);
+            const int32_t m = (int32_t)((uint32_t)acc & kMask29);
+            acc >>= kLB;
+#pragma unroll
+            for (int k = 1; k < kNL; k++) {
+                mac(acc, st[0].l[k], c0);
+                mac(acc, st[1].l[k], c1);
+                mac(acc, st[2].l[k], c2);
+                mac(acc, m, NEGP29[k]);
+                y.l[k - 1] = (int32_t)((uint32_t)acc & kMask29);
+                acc >>= kLB;
+            }
+            y.l[kNL - 1] = (int32_t)acc;
+            Fr v = finalize(mont_mul_const(y, u + 4 * kNL));
+            if (!full) v = fr_add(v, load_const(d_wit.d[r], j));
+            store_wire(wires, n, wire + 2 * j, rec, live, v);
+        }
+        small_mds(st);
+        // r2[j] = row j of the linear layer + the next round's constant
+#pragma unroll 1
+        for (int i = 0; i < 5; i++) {
+            const int j = 4 - i;
+            Fr v = finalize(mont_mul_const(st[4], u + 5 * kNL));
+            v = fr_add(v, load_const(d_wit.d[r], 5 + j));
+            store_wire(wires, n, wire + 2 * j + 1, rec, live, v);
+            rotate_right(st);
+#pragma unroll
+            for (int k = 0; k < kNL; k++) limb_fence(st[4].l[k]);
+        }
+        wire += 10;
+#pragma unroll
+        for (int w = 0; w < 5; w++)
+#pragma unroll
+            for (int k = 0; k < kNL; k++) limb_fence(st[w].l[k]);
     }
 }
 
@@ -947,6 +1073,19 @@ int hades252_perm_trace_dev_ex(const void *d_states, void *d_trace, size_t n_per
                            (hipStream_t)stream, (const uint8_t *)d_states, (uint8_t *)d_trace, n_perms);
     else
         return HADES252_ERR_INVALID_ARG;
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
+int hades252_witness_wires(void) { return HADES_WITNESS_WIRES; }
+
+int hades252_perm_witness_dev(const void *d_states, void *d_wires, size_t n_perms, void *stream) {
+    if (n_perms == 0) return HADES252_OK;
+    if (d_states == nullptr || d_wires == nullptr || n_perms > kMaxLaunchRecords || misaligned(d_states) ||
+        misaligned(d_wires))
+        return HADES252_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_perm_witness, dim3(blocks_for(n_perms)), dim3(kBlock), lds_for(5), (hipStream_t)stream,
+                       (const uint8_t *)d_states, (uint8_t *)d_wires, n_perms);
     HIP_TRY(hipGetLastError());
     return HADES252_OK;
 }

@@ -218,6 +218,18 @@ def perm_trace(states_t, kernel: int = _lib.KERNEL_DEFAULT, out=None):
     return trace
 
 
+def perm_witness(states_t, out=None):
+    """Every gate output of the reference's GadgetStrategy (src/strategies/gadget.rs:41-133) for every state:
+    [972, n, 4] int64, wire-major in gate order (include/hades252.h).  The input is left untouched."""
+    import torch
+    ptr, n, dev = _dev_buffer(states_t, STATE_BYTES, "perm_witness")
+    n_wires = _lib.lib().hades252_witness_wires()
+    wires = torch.empty((n_wires, n, 4), dtype=torch.int64, device=dev) if out is None else out
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_perm_witness_dev(ptr, wires.data_ptr(), n, _stream_ptr(dev)), "perm_witness")
+    return wires
+
+
 FR_ADD, FR_MUL, FR_SQUARE, FR_FROM_RAW = 0, 1, 2, 3
 FR_IMPL_SATURATED32, FR_IMPL_RADIX29 = 0, 1
 

@@ -93,6 +93,16 @@ int hades252_perm_trace_dev(const void *d_states, void *d_trace, size_t n_perms,
  * constant product per word) or HADES252_KERNEL_LITERAL (the reference's schedule); identical bits. */
 int hades252_perm_trace_dev_ex(const void *d_states, void *d_trace, size_t n_perms, void *stream, int kernel);
 
+/* Full gadget witness: every gate output GadgetStrategy assigns for a permutation (src/strategies/gadget.rs:41-133),
+ * hades252_witness_wires() = 972 values per state in gate order:
+ *   round 0: 5 x (w + c);  every round: per S-boxed word v^2, v^4, v^5 (5 words in a full round, the last word in a
+ *   partial round), then for j = 0..4: r1[j] = M[j][0] v0 + M[j][1] v1 + M[j][2] v2 and
+ *   r2[j] = M[j][3] v3 + M[j][4] v4 + r1[j] + (next round's constant j, 0 after the last round).
+ * d_wires receives 972 batches, wire-major: wires[g] is n_perms scalars of 32 B (Montgomery limbs).  r2 of the last
+ * round is the permutation's output.  Needs 972 * 32 * n_perms bytes; d_states is not modified. */
+int hades252_witness_wires(void);
+int hades252_perm_witness_dev(const void *d_states, void *d_wires, size_t n_perms, void *stream);
+
 /* ---- the trait's per-operation methods, batched on device ------------------------------- */
 /* Strategy::add_round_key (src/strategies/scalar.rs:23-30).  The trait method takes the constants
  * ITERATOR (src/strategies.rs:33-41, :50-52); `cursor` is its position: word w of every state +=

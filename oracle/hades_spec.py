@@ -190,6 +190,61 @@ def perm(words: list[int], trace: list | None = None) -> list[int]:
     return st
 
 
+def perm_gadget(words: list[int], wires: list | None = None) -> list[int]:
+    """The witness values ``GadgetStrategy`` assigns when the trait's provided ``perm``
+    (src/strategies.rs:140-157) drives ITS overrides -- a different schedule of the same permutation:
+      * add_round_key (src/strategies/gadget.rs:41-57) adds constants in the FIRST round only
+        (``self.count == 0``); every later round key is appended to the previous linear layer;
+      * quintic_s_box (:59-69): three multiplication gates v2 = v*v, v4 = v2*v2, v5 = v4*v;
+      * mul_matrix (:71-133): ``count += 1``; per output row two addition gates,
+        r1 = M[j][0] v0 + M[j][1] v1 + M[j][2] v2 and r2 = M[j][3] v3 + M[j][4] v4 + r1 + c with
+        c = next round constant while ``count < rounds()``, else 0.
+    The reference's own tests assert that this equals ``ScalarStrategy::perm`` on the same input
+    (``preimage`` / ``preimage_constant``, gadget.rs:166-175, :207-244); tests/test_oracle.py repeats that
+    check between this function and ``perm`` -- the one cross-check of the round/constant schedule the
+    reference itself holds.  ``wires`` (a list) receives every gate output in gate order (972 values)."""
+    if len(words) != WIDTH:
+        raise ValueError("Hades252 state must have exactly WIDTH words")
+    ark, mds = round_constants(), mds_matrix()
+    rounds = TOTAL_FULL_ROUNDS + PARTIAL_ROUNDS
+    st = list(words)
+    cur = 0
+    count = 0
+
+    def emit(v):
+        if wires is not None:
+            wires.append(v)
+        return v
+
+    def sbox(v):
+        v2 = emit(v * v % P)
+        v4 = emit(v2 * v2 % P)
+        return emit(v4 * v % P)
+
+    for r in range(rounds):
+        full = r < TOTAL_FULL_ROUNDS // 2 or r >= TOTAL_FULL_ROUNDS // 2 + PARTIAL_ROUNDS
+        if count == 0:
+            for w in range(WIDTH):
+                st[w] = emit((st[w] + ark[cur]) % P)
+                cur += 1
+        if full:
+            st = [sbox(v) for v in st]
+        else:
+            st[WIDTH - 1] = sbox(st[WIDTH - 1])
+        count += 1
+        result = [0] * WIDTH
+        for j in range(WIDTH):
+            c = 0
+            if count < rounds:
+                c = ark[cur]
+                cur += 1
+            r1 = emit((mds[j][0] * st[0] + mds[j][1] * st[1] + mds[j][2] * st[2]) % P)
+            result[j] = emit((mds[j][3] * st[3] + mds[j][4] * st[4] + r1 + c) % P)
+        st = result
+    assert cur == WIDTH * rounds
+    return st
+
+
 # --------------------------------------------------------------------------------------
 # Memory-format helpers (BlsScalar = 4 x u64 LE limbs of value*R mod P)
 # --------------------------------------------------------------------------------------

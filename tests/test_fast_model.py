@@ -235,6 +235,72 @@ def test_coop_model_matches_spec_oracle():
         assert got == [S.to_mont(v) for v in S.perm(vals)]
 
 
+def witness_model(mont_vals):
+    """Limb-exact replay of k_perm_witness: the rounds of k_perm_fast with every gate output of the reference's
+    GadgetStrategy un-scaled on the way (hades252_amd/_derive.py::witness_schedule)."""
+    sch, ws = D.fast_schedule(), D.witness_schedule()
+    st = [D.to_limbs29(v) for v in mont_vals]
+    wires = []
+
+    def emit(x, factor, add=0):
+        wires.append((finalize_model(x, factor) + add * S.R) % P)
+
+    for r in range(D.ROUNDS):
+        full = D.is_full_round(r)
+        w = ws[r]
+        a, k = (sch["full"][r], None) if full else sch["part"][r]
+        for i in (range(5) if full else (4,)):
+            st[i] = [x + y for x, y in zip(st[i], D.to_balanced29(a[i]))]
+        if r == 0:
+            for i in range(5):
+                emit(st[i], w["u_in"])
+        for i in (range(5) if full else (4,)):
+            v2 = mont_fips(st[i], st[i], True)
+            emit(v2, w["u2"])
+            v4 = mont_fips(v2, v2, True)
+            emit(v4, w["u4"])
+            v5 = mont_fips(v4, st[i])
+            if not full:
+                v5 = mont_fips(v5, D.to_limbs29(k))
+            emit(v5, w["u5"])
+            st[i] = v5
+        # three-term partial sums, one-limb Montgomery step, normalised (same pass as small_mds with 3 columns)
+        y1 = []
+        for j in range(5):
+            acc = sum(st[c][0] * D.MDS_SMALL[j][c] for c in range(3))
+            m = acc & MASK
+            acc >>= LB
+            out = [0] * NL
+            for kk in range(1, NL):
+                acc += sum(st[c][kk] * D.MDS_SMALL[j][c] for c in range(3)) - m * P29[kk]
+                assert abs(acc) < (1 << 60)
+                out[kk - 1] = acc & MASK
+                acc >>= LB
+            assert -I31 <= acc < I31
+            out[NL - 1] = acc
+            assert normalised(out)
+            y1.append(out)
+        st = small_mds(st)
+        for j in range(5):
+            emit(y1[j], w["w1"], w["d1"][j])
+            emit(st[j], w["u_post"], w["d2"][j])
+    return wires
+
+
+def test_witness_model_matches_gadget_schedule():
+    """Every one of the 972 gate outputs of the reference's GadgetStrategy (oracle: hades_spec.perm_gadget,
+    src/strategies/gadget.rs:41-133) from the scale-tracked rounds."""
+    rng = random.Random(53)
+    assert D.WITNESS_WIRES == 972
+    for vals in ([5000] * 5, [P - 1, 0, 1, P - 2, 2], [rng.randrange(P) for _ in range(5)]):
+        spec = []
+        S.perm_gadget(vals, spec)
+        got = witness_model([S.to_mont(v) for v in vals])
+        assert len(got) == len(spec) == 972
+        bad = [i for i in range(972) if got[i] != S.to_mont(spec[i])]
+        assert not bad, bad[:10]
+
+
 def test_product_bounds_adversarial():
     """Operand limbs at the lazy extremes (positive and mixed-sign): no signed 64-bit overflow."""
     hi_limb = LAZY - 1

@@ -184,6 +184,41 @@ def test_perm_trace_fast_2pow16_digest(torch_cuda, H):
     assert torch.equal(fast[66].reshape(-1), out.reshape(-1))
 
 
+def test_perm_witness_all_gadget_wires(torch_cuda, H, oracle):
+    """hades252_perm_witness_dev: all 972 gate outputs of the reference's GadgetStrategy per state
+    (src/strategies/gadget.rs:41-133) vs the spec oracle's restatement of that schedule, on edge and random
+    states; then batch-wide identities on 5 000 states: r2 of the last round == perm output, and every S-box
+    triple satisfies v4 == v2^2 through the device field ops."""
+    torch = torch_cuda
+    rng = random.Random(17)
+    cases = [[5000] * 5, [0] * 5, [P - 1] * 5, [1, 2, 3, 4, 5]] + [[rng.randrange(P) for _ in range(5)] for _ in range(6)]
+    n_pad = 70                                  # more than one wave, ragged
+    vals = cases + [[rng.randrange(P) for _ in range(5)] for _ in range(n_pad - len(cases))]
+    inp = np.array([l for st in vals for v in st for l in limbs_of(S.to_mont(v))], dtype=np.uint64)
+    dev = to_dev(torch, inp)
+    wires = H.perm_witness(dev)
+    assert tuple(wires.shape) == (972, n_pad, 4)
+    assert (to_host(dev) == inp).all()                       # input untouched
+    host = wires.cpu().numpy().view(np.uint64).reshape(972, n_pad, 4)
+    for i in list(range(len(cases))) + [63, 64, 69]:
+        spec = []
+        S.perm_gadget(vals[i], spec)
+        got = [int_of(host[g, i]) for g in range(972)]
+        bad = [g for g in range(972) if got[g] != S.to_mont(spec[g])]
+        assert not bad, (i, bad[:8])
+    # batch-wide identities
+    n = 5000
+    st = H.gen_b(5 * n, "cuda")
+    w = H.perm_witness(st)
+    out = st.clone()
+    H.ScalarStrategy().perm(out)
+    last = torch.stack([w[962 + 2 * j + 1] for j in range(5)], dim=1)       # r2[j] of round 66
+    assert torch.equal(last.reshape(-1), out.reshape(-1))
+    for g in (5, 8, 17, 20 + 10, 5 + 15 + 10 + 15 + 10):                    # some v2 wires (rounds 0, 0, 0, 1, 2)
+        v2, v4 = w[g].contiguous(), w[g + 1].contiguous()
+        assert torch.equal(H.fr_op(H.FR_SQUARE, v2), v4)
+
+
 # ---------------------------------------------------------------------------------------------
 # variable-length sponge
 # ---------------------------------------------------------------------------------------------

@@ -69,6 +69,22 @@ def test_hades_det_like_reference(oracle):
     assert (a == b).all() and not (a == c).all()
 
 
+def test_scalar_equals_gadget_like_reference():
+    """The reference's `preimage` / `preimage_constant` tests (src/strategies/gadget.rs:207-244) assert, inside a
+    proof, that GadgetStrategy's witness values -- a DIFFERENT schedule of the same permutation: round keys after
+    the first are appended to the previous linear layer, gadget.rs:41-57, :71-133 -- equal ScalarStrategy::perm.
+    Same check between the two restatements: it is the one cross-check of the round / constant schedule the
+    reference itself holds."""
+    rng = random.Random(2024)
+    cases = [[5000] * 5, [17] * 5, [0] * 5, [P - 1] * 5]          # [5000;5]: gadget.rs:230
+    cases += [[rng.randrange(P) for _ in range(5)] for _ in range(8)]
+    for vals in cases:
+        wires = []
+        assert S.perm_gadget(vals, wires) == S.perm(vals)
+        # (CHANGELOG.md:134-135 counts 973 gates per permutation; this schedule has 972 gate outputs)
+        assert len(wires) == 5 + 3 * (8 * 5 + 59) + 10 * 67 == 972
+
+
 def test_wrong_width_rejected():
     # the reference panics for len != WIDTH (scalar.rs:48)
     with pytest.raises(ValueError):

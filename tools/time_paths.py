@@ -107,6 +107,13 @@ for lognt in (18, 20):
         print("perm_trace %-7s n=2^%d states  %8.3f ms  %8.2f Mperm/s  (67 x 160 B written per state: %.1f GB/s)" % (name, lognt, dt * 1e3, nt / dt / 1e6, 67 * 160 * nt / dt / 1e9))
     del trace
 
+nw = 1 << 18
+st = H.gen_b(5 * nw, dev)
+wires = torch.empty((972, nw, 4), dtype=torch.int64, device=dev)
+dt = timed(lambda: H.perm_witness(st, out=wires), reps=3)
+print("perm_witness (972 gadget wires) n=2^18 states  %8.3f ms  %8.2f Mperm/s  (31 104 B written per state: %.1f GB/s)" % (dt * 1e3, nw / dt / 1e6, 972 * 32 * nw / dt / 1e9))
+del wires
+
 print("== batched fixed-length sponge (rate 4, pad with 1)")
 cap = (1 << 64) * ((1 << 256) % 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001) % 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 for length, nmsg in ((3, 1 << 22), (4, 1 << 22), (16, 1 << 20)):
