@@ -1,0 +1,19 @@
+#!/bin/bash
+# One GPU-box session: the whole GPU test tier, the timing table, the headline bench and the rocprofv3 round
+# (kernel trace + separate PMC passes on bench.py, wire-format kernels and the VALU-ceiling microbenchmark).
+#   gpurun --timeout 3600 -- 'bash tools/gpu_session.sh r2'
+set -u
+TAG=${1:-r2}
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.txt 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/pytest_gpu_$TAG.txt
+tail -4 gpurun_out/pytest_gpu_$TAG.txt
+timeout 600 ./build_tools/ubench3 > gpurun_out/ubench3_$TAG.txt 2>&1; echo "ubench3 rc=$?"
+timeout 300 ./build_tools/residency > gpurun_out/residency_$TAG.txt 2>&1; echo "residency rc=$?"
+timeout 120 ./build_tools/dfma_proto > gpurun_out/dfma_proto_$TAG.txt 2>&1; echo "dfma rc=$?"
+timeout 900 python tools/time_paths.py > gpurun_out/time_paths_$TAG.txt 2>&1; echo "time_paths rc=$?"
+timeout 600 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"
+bash tools/profile_round.sh $TAG > gpurun_out/profile_round_$TAG.log 2>&1; echo "profile rc=$?"
+timeout 600 python bench.py > gpurun_out/bench_${TAG}_after_profile.json 2>> gpurun_out/bench_$TAG.err; echo "bench2 rc=$?"
+tail -c 600 gpurun_out/bench_${TAG}_after_profile.json
