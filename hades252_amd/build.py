@@ -25,7 +25,10 @@ SOURCES = ["hades252.hip"]
 DEPS = ["hades252.hip", "fr32.cuh", "staging.cuh", "hades_literal.cuh", "hades_fast.cuh", "hades_coop.cuh",
         "hades_constants.inc", os.path.join("..", "..", "include", "hades252.h")]
 # what the dominant kernel (k_perm_fast) is made of: profiles recorded for it stay valid while these are unchanged
-PERM_FAST_DEPS = ["fr32.cuh", "staging.cuh", "hades_fast.cuh", "hades_constants.inc"]
+PERM_FAST_DEPS = ["fr32.cuh", "staging.cuh", "hades_fast.cuh"]
+# ... plus these tables of hades_constants.inc (other kernels' tables may change without touching k_perm_fast)
+PERM_FAST_TABLES = ("HADES_FAST_L", "HADES_FAST_MDS_SMALL", "HADES_NEG_P29", "HADES_TWO_P29", "HADES_FAST_ROUND_INIT",
+                    "HADES_FAST_FINAL_F")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-pthread",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
@@ -45,6 +48,14 @@ def perm_fast_hash() -> str:
     for d in PERM_FAST_DEPS:
         with open(os.path.join(CSRC, d), "rb") as f:
             h.update(d.encode() + b"\0" + f.read())
+    keep = False
+    with open(os.path.join(CSRC, "hades_constants.inc")) as f:
+        for line in f:
+            if line.startswith("#define "):
+                keep = line.split()[1] in PERM_FAST_TABLES
+            if keep:
+                h.update(line.encode())
+                keep = line.rstrip().endswith("\\")
     return h.hexdigest()
 
 
