@@ -5,6 +5,7 @@ set -u
 TAG=${1:-r1}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--steps 5 --warmup 1 --no-cpu-baseline"

@@ -1,7 +1,7 @@
 """Soak / differential test on the GPU (development + evidence, not part of pytest):
-  1. literal kernel vs shipped kernel on N_CHUNKS x 2^26 random states with different seeds
-     (digest of all outputs must agree);
-  2. every 5-tuple over a set of edge values (0, 1, p-1, R, ...), literal vs shipped, all bits.
+  1. literal kernel vs shipped kernel vs five-waves-per-state kernel on N_CHUNKS x 2^26 random states with
+     different seeds (digest of all outputs must agree);
+  2. every 5-tuple over a set of edge values (0, 1, p-1, R, ...), literal vs shipped vs cooperative, all bits.
 The literal kernel is the reference's schedule verbatim and is itself compared with the CPU
 oracle in tests/."""
 import itertools, os, sys, time
@@ -26,7 +26,10 @@ for c in range(n_chunks):
     H.gen_b(5 * n, dev, seed=seed, out=a.view(-1, 4))
     H.ScalarStrategy(1).perm(a)
     d_lit = H.digest(a)
-    ok = d_fast == d_lit
+    H.gen_b(5 * n, dev, seed=seed, out=a.view(-1, 4))
+    H.ScalarStrategy(3).perm(a)
+    d_coop = H.digest(a)
+    ok = d_fast == d_lit == d_coop
     bad += not ok
     print("chunk %2d seed %#x  %s  digest %016x" % (c, seed, "ok" if ok else "MISMATCH", d_fast[0]), flush=True)
 print("random soak: %d x 2^26 = %.3g states, mismatching chunks: %d, %.1f s" % (n_chunks, n_chunks * n, bad, time.time() - t0))
@@ -39,8 +42,10 @@ idx = np.array(list(itertools.product(range(len(edge)), repeat=5)), dtype=np.int
 states = tab[idx]                                                                          # [N,5,4]
 x = torch.from_numpy(states.view(np.int64)).to(dev).contiguous()
 y = x.clone()
+z = x.clone()
 H.ScalarStrategy(2).perm(x)
 H.ScalarStrategy(1).perm(y)
-same = torch.equal(x, y)
-print("edge 5-tuples: %d states, literal == shipped: %s" % (idx.shape[0], same))
+H.ScalarStrategy(3).perm(z)
+same = torch.equal(x, y) and torch.equal(x, z)
+print("edge 5-tuples: %d states, literal == shipped == cooperative: %s" % (idx.shape[0], same))
 sys.exit(0 if (bad == 0 and same) else 1)
