@@ -45,6 +45,9 @@ struct WitnessTables {
 __device__ const WitnessTables d_wit = {HADES_WITNESS_U_INIT, HADES_WITNESS_D_INIT};
 // generic radix-2^29 field ops (hades252_fr_op_dev)
 __device__ const int32_t d_rp_mod_p[16] = HADES_RP_MOD_P29;
+// wire format (from_bytes / to_bytes) on the same path
+__device__ const int32_t d_rp_times_r[16] = HADES_RP_TIMES_R29;
+__device__ const int32_t d_rp_over_r[16] = HADES_RP_OVER_R29;
 __device__ const int32_t d_rp2_over_r[16] = HADES_RP2_OVER_R29;
 
 constexpr int kBlock = 256;
@@ -296,40 +299,33 @@ __global__ void __launch_bounds__(kBlock) k_sbox(uint8_t *scalars, size_t n) {
     wave_store_records<1>(scalars, rec0, n, slab, st);
 }
 
-// canonical bytes <-> Montgomery limbs (32 B each way, one scalar per lane).  `out` may be `in`
-// (the host byte path converts in place): every wave loads its 64 records before storing them.
-__global__ void __launch_bounds__(kBlock) k_from_bytes(const uint8_t *in, uint8_t *out, size_t n, int *bad_count) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t *slab = wave_slab<1>(lds);
-    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
-    Fr st[1];
-    wave_load_records<1>(in, rec0, n, slab, st);
-    bool ok = fr_is_canonical(st[0]);
-    Fr r2;
+// canonical bytes <-> Montgomery limbs (BlsScalar::from_bytes / to_bytes): 64 B of HBM traffic and ONE constant
+// product per scalar.  The product runs on the radix-2^29 path (mont_mul_const: 153 multiply-adds; the saturated
+// 8x32 product these kernels used in round 1 is ~620 instructions and made them VALU-bound at 3.4-4.5 TB/s).
+// No LDS: every lane reads and writes its own 32 bytes with two 16-byte accesses -- a wave's two instructions
+// together cover 2 KiB contiguous, the second hits the lines the first fetched -- and takes kWirePerThread scalars
+// in a grid-stride loop to keep more bytes in flight.  `out` may be `in` (lane-private in-place update).
+constexpr int kWirePerThread = 4;
+template <int MODE>   // 0 = to_bytes (x / 2^256), 1 = from_bytes (a * 2^256, inputs >= p rejected)
+__global__ void __launch_bounds__(kBlock) k_wire(const uint8_t *in, uint8_t *out, size_t n, int *bad_count) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    const int32_t *factor = MODE == 1 ? d_rp_times_r : d_rp_over_r;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(in + i * 32);
+        uint4 lo = p[0], hi = p[1];
+        Fr a;
+        a.l[0] = lo.x; a.l[1] = lo.y; a.l[2] = lo.z; a.l[3] = lo.w;
+        a.l[4] = hi.x; a.l[5] = hi.y; a.l[6] = hi.z; a.l[7] = hi.w;
+        Fr m = finalize(mont_mul_const(to_f29(a), factor));
+        if (MODE == 1 && !fr_is_canonical(a)) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) r2.l[i] = d_r2[i];
-    Fr m = fr_mul(st[0], r2);
-    if (!ok) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) m.l[i] = 0;
-        size_t rec = rec0 + (threadIdx.x & (kWave - 1));
-        if (bad_count != nullptr && rec < n) atomicAdd(bad_count, 1);
+            for (int k = 0; k < 8; k++) m.l[k] = 0;
+            if (bad_count != nullptr) atomicAdd(bad_count, 1);
+        }
+        uint4 *q = reinterpret_cast<uint4 *>(out + i * 32);
+        q[0] = make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]);
+        q[1] = make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]);
     }
-    st[0] = m;
-    wave_store_records<1>(out, rec0, n, slab, st);
-}
-
-__global__ void __launch_bounds__(kBlock) k_to_bytes(const uint8_t *in, uint8_t *out, size_t n) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t *slab = wave_slab<1>(lds);
-    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
-    Fr st[1];
-    wave_load_records<1>(in, rec0, n, slab, st);
-    Fr one;
-#pragma unroll
-    for (int i = 0; i < 8; i++) one.l[i] = (i == 0);
-    st[0] = fr_mul(st[0], one);              // a * 1 / R = canonical value
-    wave_store_records<1>(out, rec0, n, slab, st);
 }
 
 // The shipped hot path: one permutation per lane, scale-tracked formulation (hades_fast.cuh).
@@ -1173,8 +1169,8 @@ int hades252_from_bytes_dev(const void *d_bytes, void *d_limbs, size_t n_scalars
     if (d_bytes == nullptr || d_limbs == nullptr || n_scalars > kMaxLaunchRecords || misaligned(d_bytes) ||
         misaligned(d_limbs))
         return HADES252_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_from_bytes, dim3(blocks_for(n_scalars)), dim3(kBlock), lds_for(1), (hipStream_t)stream,
-                       (const uint8_t *)d_bytes, (uint8_t *)d_limbs, n_scalars, d_bad_count);
+    hipLaunchKernelGGL(k_wire<1>, dim3(blocks_for((n_scalars + kWirePerThread - 1) / kWirePerThread)), dim3(kBlock), 0,
+                       (hipStream_t)stream, (const uint8_t *)d_bytes, (uint8_t *)d_limbs, n_scalars, d_bad_count);
     HIP_TRY(hipGetLastError());
     return HADES252_OK;
 }
@@ -1184,8 +1180,8 @@ int hades252_to_bytes_dev(const void *d_limbs, void *d_bytes, size_t n_scalars, 
     if (d_bytes == nullptr || d_limbs == nullptr || n_scalars > kMaxLaunchRecords || misaligned(d_bytes) ||
         misaligned(d_limbs))
         return HADES252_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_to_bytes, dim3(blocks_for(n_scalars)), dim3(kBlock), lds_for(1), (hipStream_t)stream,
-                       (const uint8_t *)d_limbs, (uint8_t *)d_bytes, n_scalars);
+    hipLaunchKernelGGL(k_wire<0>, dim3(blocks_for((n_scalars + kWirePerThread - 1) / kWirePerThread)), dim3(kBlock), 0,
+                       (hipStream_t)stream, (const uint8_t *)d_limbs, (uint8_t *)d_bytes, n_scalars, (int *)nullptr);
     HIP_TRY(hipGetLastError());
     return HADES252_OK;
 }
