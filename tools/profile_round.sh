@@ -28,7 +28,7 @@ for d in ("pmc_wire_fetch", "pmc_wire_write"):
     for f in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r.get("Kernel_Name", "")
-            if "bytes" in k:
+            if "k_wire" in k or "bytes" in k:
                 acc.setdefault((k.split("(")[0], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
 for (k, c), v in sorted(acc.items()):
     avg = sum(v) / len(v)
