@@ -45,6 +45,10 @@ struct WitnessTables {
 __device__ const WitnessTables d_wit = {HADES_WITNESS_U_INIT, HADES_WITNESS_D_INIT};
 // generic radix-2^29 field ops (hades252_fr_op_dev)
 __device__ const int32_t d_rp_mod_p[16] = HADES_RP_MOD_P29;
+// per-operation kernels on the same path (hades252_amd/_derive.py)
+__device__ const int32_t d_op_k[16] = HADES_OP_K29;
+__device__ const int32_t d_op_w[16] = HADES_OP_W29;
+__device__ const int32_t d_op_w_full[16] = HADES_OP_W_FULL29;
 // wire format (from_bytes / to_bytes) on the same path
 __device__ const int32_t d_rp_times_r[16] = HADES_RP_TIMES_R29;
 __device__ const int32_t d_rp_over_r[16] = HADES_RP_OVER_R29;
@@ -62,6 +66,16 @@ __device__ __forceinline__ uint8_t *wave_slab(uint8_t *lds) {
 }
 
 enum Op { OP_PERM = 0, OP_ARK, OP_MDS, OP_FULL, OP_PARTIAL };
+
+// st[4] <- st[3] <- ... <- st[0] <- st[4]: loops over the five words rotate the state through ONE code body
+__device__ __forceinline__ void rotate_right(F29 (&st)[5]) {
+    const F29 t = st[4];
+    st[4] = st[3];
+    st[3] = st[2];
+    st[2] = st[1];
+    st[1] = st[0];
+    st[0] = t;
+}
 
 template <int OP>
 __global__ void __launch_bounds__(kBlock) k_states_literal(uint8_t *states, size_t n, int cursor) {
@@ -145,14 +159,6 @@ __device__ __forceinline__ void store_wire(uint8_t *wires, size_t n, int wire, s
         q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
         q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
     }
-}
-__device__ __forceinline__ void rotate_right(F29 (&st)[5]) {
-    const F29 t = st[4];
-    st[4] = st[3];
-    st[3] = st[2];
-    st[2] = st[1];
-    st[1] = st[0];
-    st[0] = t;
 }
 
 __global__ void __launch_bounds__(kBlock, 3) k_perm_witness(const uint8_t *__restrict__ states,
@@ -289,13 +295,50 @@ __global__ void __launch_bounds__(kBlock) k_fr_op(const uint8_t *a, const uint8_
     wave_store_records<1>(out, rec0, n, slab, r);
 }
 
+// The trait's per-operation methods on the radix-2^29 path: same field elements as the literal forms above (kept
+// for add_round_key, which is five additions), a sixth to a tenth of the instructions -- mul_matrix is the
+// small-integer layer + one un-scaling product per word instead of 25 full products.  Round keys are added in the
+// memory format first (any cursor over all 960 constants), so the result of every method is the unique reduced
+// BlsScalar, bit-identical to the literal kernels and the oracle.
+template <int OP>
+__global__ void __launch_bounds__(kBlock, 3) k_states_fast(uint8_t *states, size_t n, int cursor) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<5>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr in[5];
+    wave_load_records<5>(states, rec0, n, slab, in);
+    if constexpr (OP != OP_MDS) {
+        LiteralView V{d_ark_mont, d_mds_mont};
+        lit_add_round_key(V, cursor, in);
+    }
+    F29 st[5];
+#pragma unroll
+    for (int w = 0; w < 5; w++) st[w] = to_f29(in[w]);
+    if constexpr (OP == OP_FULL) {
+#pragma unroll 1
+        for (int i = 0; i < 5; i++) {                 // one S-box body, the state rotates through it
+            st[4] = sbox29(st[4]);
+            rotate_right(st);
+#pragma unroll
+            for (int k = 0; k < kNL; k++) limb_fence(st[4].l[k]);
+        }
+    }
+    if constexpr (OP == OP_PARTIAL) st[4] = mont_mul_const(sbox29(st[4]), d_op_k);
+    small_mds(st);
+    const int32_t *u = OP == OP_FULL ? d_op_w_full : d_op_w;
+    Fr out[5];
+#pragma unroll
+    for (int w = 0; w < 5; w++) out[w] = finalize(mont_mul_const(st[w], u));
+    wave_store_records<5>(states, rec0, n, slab, out);
+}
+
 __global__ void __launch_bounds__(kBlock) k_sbox(uint8_t *scalars, size_t n) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *slab = wave_slab<1>(lds);
     size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
     Fr st[1];
     wave_load_records<1>(scalars, rec0, n, slab, st);
-    st[0] = lit_quintic_s_box(st[0]);
+    st[0] = finalize(mont_mul_const(sbox29(to_f29(st[0])), d_op_k));
     wave_store_records<1>(scalars, rec0, n, slab, st);
 }
 
@@ -1103,8 +1146,8 @@ static int states_op_at(int op, void *d_states, size_t n_states, long cursor, vo
     uint8_t *p = (uint8_t *)d_states;
     switch (op) {
         case OP_ARK: hipLaunchKernelGGL(k_states_literal<OP_ARK>, grid, block, lds_for(5), s, p, n_states, (int)cursor); break;
-        case OP_FULL: hipLaunchKernelGGL(k_states_literal<OP_FULL>, grid, block, lds_for(5), s, p, n_states, (int)cursor); break;
-        default: hipLaunchKernelGGL(k_states_literal<OP_PARTIAL>, grid, block, lds_for(5), s, p, n_states, (int)cursor); break;
+        case OP_FULL: hipLaunchKernelGGL(k_states_fast<OP_FULL>, grid, block, lds_for(5), s, p, n_states, (int)cursor); break;
+        default: hipLaunchKernelGGL(k_states_fast<OP_PARTIAL>, grid, block, lds_for(5), s, p, n_states, (int)cursor); break;
     }
     HIP_TRY(hipGetLastError());
     return HADES252_OK;
@@ -1148,7 +1191,7 @@ int hades252_fr_op_dev(int op, int impl, const void *d_a, const void *d_b, void 
 int hades252_mul_matrix_dev(void *d_states, size_t n_states, void *stream) {
     if (n_states == 0) return HADES252_OK;
     if (d_states == nullptr || n_states > kMaxLaunchRecords || misaligned(d_states)) return HADES252_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_states_literal<OP_MDS>, dim3(blocks_for(n_states)), dim3(kBlock), lds_for(5),
+    hipLaunchKernelGGL(k_states_fast<OP_MDS>, dim3(blocks_for(n_states)), dim3(kBlock), lds_for(5),
                        (hipStream_t)stream, (uint8_t *)d_states, n_states, 0);
     HIP_TRY(hipGetLastError());
     return HADES252_OK;

@@ -301,6 +301,29 @@ def test_witness_model_matches_gadget_schedule():
         assert not bad, bad[:10]
 
 
+def test_per_op_models_match_spec_oracle():
+    """k_states_fast / k_sbox: the trait's per-operation methods on the radix-2^29 path."""
+    rng = random.Random(61)
+    op = D.per_op_constants()
+    mds = S.mds_matrix()
+    for vals in ([1] * 5, [P - 1, 0, 1, P - 2, 2], [rng.randrange(P) for _ in range(5)]):
+        st = [D.to_limbs29(S.to_mont(v)) for v in vals]
+        # quintic_s_box
+        assert finalize_model(sbox(st[0]), op["k"]) == S.to_mont(S.quintic_s_box(vals[0]))
+        # mul_matrix
+        exp = [sum(mds[i][j] * vals[j] for j in range(5)) % P for i in range(5)]
+        assert [finalize_model(x, op["w"]) for x in small_mds(st)] == [S.to_mont(v) for v in exp]
+        # full round body after the round key: S-box everywhere, matrix
+        sb = [S.quintic_s_box(v) for v in vals]
+        exp = [sum(mds[i][j] * sb[j] for j in range(5)) % P for i in range(5)]
+        assert [finalize_model(x, op["w_full"]) for x in small_mds([sbox(x) for x in st])] == [S.to_mont(v) for v in exp]
+        # partial round body: S-box on the last word, re-scaled with K, matrix
+        pb = vals[:4] + [S.quintic_s_box(vals[4])]
+        exp = [sum(mds[i][j] * pb[j] for j in range(5)) % P for i in range(5)]
+        pst = st[:4] + [mont_fips(sbox(st[4]), D.to_limbs29(op["k"]))]
+        assert [finalize_model(x, op["w"]) for x in small_mds(pst)] == [S.to_mont(v) for v in exp]
+
+
 def test_product_bounds_adversarial():
     """Operand limbs at the lazy extremes (positive and mixed-sign): no signed 64-bit overflow."""
     hi_limb = LAZY - 1

@@ -114,6 +114,20 @@ dt = timed(lambda: H.perm_witness(st, out=wires), reps=3)
 print("perm_witness (972 gadget wires) n=2^18 states  %8.3f ms  %8.2f Mperm/s  (31 104 B written per state: %.1f GB/s)" % (dt * 1e3, nw / dt / 1e6, 972 * 32 * nw / dt / 1e9))
 del wires
 
+print("== the trait's per-operation methods, batched (n = 2^22 states / 2^24 scalars)")
+n = 1 << 22
+stt = H.gen_b(5 * n, dev)
+sc = H.gen_b(1 << 24, dev)
+strat = H.ScalarStrategy()
+for name, fn, units in (("add_round_key", lambda: strat.add_round_key(H.RoundConstantsIter(7), stt), n),
+                        ("mul_matrix", lambda: strat.mul_matrix(H.RoundConstantsIter(), stt), n),
+                        ("apply_full_round", lambda: strat.apply_full_round(H.RoundConstantsIter(0), stt), n),
+                        ("apply_partial_round", lambda: strat.apply_partial_round(H.RoundConstantsIter(20), stt), n),
+                        ("quintic_s_box", lambda: strat.quintic_s_box(sc), 1 << 24)):
+    dt = timed(fn, reps=5)
+    print("%-20s %8.3f ms  %8.2f G units/s" % (name, dt * 1e3, units / dt / 1e9))
+del stt, sc
+
 print("== batched fixed-length sponge (rate 4, pad with 1)")
 cap = (1 << 64) * ((1 << 256) % 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001) % 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 for length, nmsg in ((3, 1 << 22), (4, 1 << 22), (16, 1 << 20)):
