@@ -128,7 +128,9 @@ def launch_ranks(args) -> int:
     import subprocess
     from hades252_amd import build
     build.build(verbose=False)          # once, so the ranks do not race to compile
-    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, stdout=subprocess.DEVNULL)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oracle_lib.build()                  # the checker, likewise
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]

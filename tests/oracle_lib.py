@@ -18,10 +18,36 @@ _u8p = ctypes.POINTER(ctypes.c_uint8)
 
 
 def build():
-    src = os.path.join(ORACLE_DIR, "hades_oracle.c")
-    hdr = os.path.join(ORACLE_DIR, "hades_oracle_constants.h")
-    if (not os.path.exists(SO)) or os.path.getmtime(SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.run(["make", "-C", ORACLE_DIR], check=True, stdout=subprocess.DEVNULL)
+    """Build the oracle library if it is missing or stale.  Staleness is decided by a content hash of the sources
+    (a copied tree does not preserve mtimes) and builds are serialised with a file lock: the ranks of a multi-GPU
+    bench all call this at once."""
+    import fcntl
+    import hashlib
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("hades_oracle.c", "hades_oracle_constants.h", "Makefile")]
+    h = hashlib.sha256()
+    for f in srcs:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    want = h.hexdigest()
+    out_dir = os.path.join(ORACLE_DIR, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    stamp = os.path.join(out_dir, "libhades_oracle.so.stamp")
+
+    def fresh():
+        return os.path.exists(SO) and os.path.exists(stamp) and open(stamp).read().strip() == want
+
+    if fresh():
+        return SO
+    with open(os.path.join(out_dir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not fresh():
+                subprocess.run(["make", "-B", "-C", ORACLE_DIR], check=True, stdout=subprocess.DEVNULL)
+                with open(stamp + ".tmp", "w") as f:
+                    f.write(want + "\n")
+                os.replace(stamp + ".tmp", stamp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return SO
 
 
