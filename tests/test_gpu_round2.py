@@ -219,6 +219,29 @@ def test_perm_witness_all_gadget_wires(torch_cuda, H, oracle):
         assert torch.equal(H.fr_op(H.FR_SQUARE, v2), v4)
 
 
+def test_witness_rows_equal_trace_plus_next_round_key(torch_cuda, H, oracle):
+    """Two independent kernels at scale: for every round r and word j, the gadget's row wire r2[r][j] must equal the
+    per-round trace state + the NEXT round's constant (src/strategies/gadget.rs:102-129), on 2^14 states."""
+    torch = torch_cuda
+    n = 1 << 14
+    st = H.gen_b(5 * n, "cuda", first_elem=12345)
+    wires = H.perm_witness(st)
+    trace = H.perm_trace(st)                                   # [67, n, 5, 4]
+    base = 5                                                   # wires of round 0's key additions
+    for r in range(67):
+        full = r < 4 or r >= 63
+        base += 15 if full else 3                              # S-box wires of this round
+        for j in range(5):
+            row = wires[base + 2 * j + 1]
+            state = trace[r, :, j, :].contiguous()
+            if r < 66:
+                c = scalars_dev(torch, [oracle.round_constant(5 * (r + 1) + j)]).expand(n, 4).contiguous()
+                state = H.fr_op(H.FR_ADD, state, c)
+            assert torch.equal(row, state), (r, j)
+        base += 10
+    assert base == 972
+
+
 # ---------------------------------------------------------------------------------------------
 # variable-length sponge
 # ---------------------------------------------------------------------------------------------
