@@ -545,6 +545,10 @@ __global__ void __launch_bounds__(kBlock) k_merkle_open(const uint8_t *__restric
     const int rem = (int)(tid - t * per_query);
     const int l = rem / ((ARITY - 1) * 2), sh = rem - l * (ARITY - 1) * 2, s = sh >> 1, half = sh & 1;
     size_t node = indices[t];                 // index of the path node at level l (level 0 = leaves)
+    if (node >= n_leaves) {                   // never read outside the tree: an invalid index yields an all-zero path
+        *reinterpret_cast<uint4 *>(paths + tid * 16) = make_uint4(0, 0, 0, 0);
+        return;
+    }
     const uint8_t *level = leaves;
     size_t level_n = n_leaves, off = 0;
     for (int i = 0; i < l; i++) {

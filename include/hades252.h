@@ -159,7 +159,8 @@ int hades252_merkle_build_dev(const void *d_leaves, size_t n_leaves, int arity, 
                               void *d_tree, void *stream);
 /* Openings (authentication paths) from a built tree: for query t with leaf index d_indices[t] (device u64) and
  * level l = 0 .. depth-1, the arity-1 siblings of the path node, in child order with the node's own position
- * (index / arity^l) % arity skipped: d_paths[t][l][s], 32 B each, depth * (arity-1) * 32 bytes per query. */
+ * (index / arity^l) % arity skipped: d_paths[t][l][s], 32 B each, depth * (arity-1) * 32 bytes per query.
+ * An index >= n_leaves yields an all-zero path (nothing outside the tree is read). */
 int hades252_merkle_open_dev(const void *d_leaves, const void *d_tree, size_t n_leaves, int arity,
                              const uint64_t *d_indices, size_t n_queries, void *d_paths, void *stream);
 /* arity-4 forms (BASELINE config 4) */

@@ -364,6 +364,14 @@ def test_merkle_openings(torch_cuda, H, oracle, arity, depth):
             assert (oracle.merkle_verify_path(leaves[4 * i:4 * i + 4], i, host[t], arity, tag, 1) == root).all()
     with pytest.raises(IndexError):
         H.merkle_open(dl, tree, arity, to_dev(torch, np.array([n], dtype=np.uint64)))
+    # the C ABI itself never reads outside the tree: an out-of-range index gives an all-zero path
+    from hades252_amd import _lib
+    bad = to_dev(torch, np.array([n + 5, 1], dtype=np.uint64))
+    out = torch.full((2, depth, arity - 1, 4), -1, dtype=torch.int64, device="cuda")
+    assert _lib.lib().hades252_merkle_open_dev(dl.data_ptr(), tree.data_ptr(), n, arity, bad.data_ptr(), 2,
+                                                out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert int(out[0].abs().sum().item()) == 0 and torch.equal(out[1], paths[1])
 
 
 def test_merkle_argument_errors(torch_cuda, H, hades_lib):
