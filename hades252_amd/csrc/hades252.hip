@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_sponge(const uint8_t *__restrict_
                                                       const uint64_t *__restrict__ offsets,
                                                       const uint64_t *__restrict__ lengths,
                                                       uint8_t *__restrict__ digests, size_t n_msgs, size_t fixed_len,
-                                                      Fr capacity, int pad_mode) {
+                                                      Fr capacity, int pad_mode, size_t n_scalars, int *bad_count) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *slab = wave_slab<4>(lds);
     constexpr int kRec = lds_rec_bytes(4);
@@ -600,7 +600,12 @@ __global__ void __launch_bounds__(kBlock, 3) k_sponge(const uint8_t *__restrict_
     const size_t me = rec0 + lane;
     const bool live = me < n_msgs;
     const uint64_t off = live ? (offsets != nullptr ? offsets[me] : (uint64_t)me * fixed_len) : 0;
-    const uint64_t len = live ? (lengths != nullptr ? lengths[me] : (uint64_t)fixed_len) : 0;
+    uint64_t len = live ? (lengths != nullptr ? lengths[me] : (uint64_t)fixed_len) : 0;
+    // a message that does not lie inside the pool is never read: it is hashed as the empty message and counted
+    if (live && (off > n_scalars || len > n_scalars - off)) {
+        len = 0;
+        if (bad_count != nullptr) atomicAdd(bad_count, 1);
+    }
     uint64_t blocks = (len + (pad_mode == 1 ? 1 : 0) + 3) / 4;
     if (blocks == 0) blocks = 1;
     if (!live) blocks = 0;
@@ -1269,7 +1274,8 @@ int hades252_merkle4_level_dev(const void *d_children, void *d_parents, size_t n
 }
 
 static int sponge_launch(const void *d_scalars, const uint64_t *d_offsets, const uint64_t *d_lengths, size_t n_msgs,
-                         size_t fixed_len, const uint64_t capacity_mont[4], int pad_mode, void *d_digests, void *stream) {
+                         size_t fixed_len, const uint64_t capacity_mont[4], int pad_mode, void *d_digests, void *stream,
+                         size_t n_scalars, int *d_bad_count) {
     Fr cap;
     for (int k = 0; k < 4; k++) {
         cap.l[2 * k] = (uint32_t)capacity_mont[k];
@@ -1277,7 +1283,7 @@ static int sponge_launch(const void *d_scalars, const uint64_t *d_offsets, const
     }
     hipLaunchKernelGGL(k_sponge, dim3(blocks_for(n_msgs)), dim3(kBlock), lds_for(4), (hipStream_t)stream,
                        (const uint8_t *)d_scalars, d_offsets, d_lengths, (uint8_t *)d_digests, n_msgs, fixed_len, cap,
-                       pad_mode);
+                       pad_mode, n_scalars, d_bad_count);
     HIP_TRY(hipGetLastError());
     return HADES252_OK;
 }
@@ -1288,17 +1294,20 @@ int hades252_sponge_hash_dev(const void *d_msgs, size_t n_msgs, size_t msg_len, 
     if (d_digests == nullptr || capacity_mont == nullptr || (d_msgs == nullptr && msg_len > 0) ||
         (pad_mode != 0 && pad_mode != 1) || n_msgs > kMaxLaunchRecords || misaligned(d_msgs) || misaligned(d_digests))
         return HADES252_ERR_INVALID_ARG;
-    return sponge_launch(d_msgs, nullptr, nullptr, n_msgs, msg_len, capacity_mont, pad_mode, d_digests, stream);
+    return sponge_launch(d_msgs, nullptr, nullptr, n_msgs, msg_len, capacity_mont, pad_mode, d_digests, stream,
+                         n_msgs * msg_len, nullptr);
 }
 
-int hades252_sponge_hash_var_dev(const void *d_scalars, const uint64_t *d_offsets, const uint64_t *d_lengths,
-                                 size_t n_msgs, const uint64_t capacity_mont[4], int pad_mode, void *d_digests,
-                                 void *stream) {
+int hades252_sponge_hash_var_dev(const void *d_scalars, size_t n_scalars, const uint64_t *d_offsets,
+                                 const uint64_t *d_lengths, size_t n_msgs, const uint64_t capacity_mont[4], int pad_mode,
+                                 void *d_digests, int *d_bad_count, void *stream) {
     if (n_msgs == 0) return HADES252_OK;
     if (d_digests == nullptr || capacity_mont == nullptr || d_offsets == nullptr || d_lengths == nullptr ||
-        (pad_mode != 0 && pad_mode != 1) || n_msgs > kMaxLaunchRecords || misaligned(d_scalars) || misaligned(d_digests))
+        (d_scalars == nullptr && n_scalars > 0) || (pad_mode != 0 && pad_mode != 1) || n_msgs > kMaxLaunchRecords ||
+        misaligned(d_scalars) || misaligned(d_digests))
         return HADES252_ERR_INVALID_ARG;
-    return sponge_launch(d_scalars, d_offsets, d_lengths, n_msgs, 0, capacity_mont, pad_mode, d_digests, stream);
+    return sponge_launch(d_scalars, d_offsets, d_lengths, n_msgs, 0, capacity_mont, pad_mode, d_digests, stream,
+                         n_scalars, d_bad_count);
 }
 
 size_t hades252_merkle_tree_bytes(size_t n_leaves, int arity) {

@@ -392,9 +392,12 @@ def sponge_hash_var(scalars_t, offsets_t, lengths_t, capacity_mont: int, pad_mod
     if n != n2:
         raise ValueError("sponge_hash_var: offsets and lengths differ in size")
     out = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.lib().hades252_sponge_hash_var_dev(sptr, optr, lptr, n, _tag_arr(capacity_mont), pad_mode,
-                                                      out.data_ptr(), _stream_ptr(dev)), "sponge_hash_var")
+        check(_lib.lib().hades252_sponge_hash_var_dev(sptr, n_scalars, optr, lptr, n, _tag_arr(capacity_mont), pad_mode,
+                                                      out.data_ptr(), bad.data_ptr(), _stream_ptr(dev)), "sponge_hash_var")
+    if int(bad.item()) != 0:
+        raise IndexError("sponge_hash_var: %d message(s) reach outside the scalar pool" % int(bad.item()))
     return out
 
 

@@ -181,10 +181,12 @@ int hades252_sponge_hash_dev(const void *d_msgs, size_t n_msgs, size_t msg_len, 
                              int pad_mode, void *d_digests, void *stream);
 /* Variable-length batch: message i = d_scalars[d_offsets[i] .. d_offsets[i] + d_lengths[i]) (offsets and
  * lengths in scalars, device arrays of n_msgs u64; messages may overlap or leave gaps; length 0 allowed).
+ * n_scalars = size of the pool: a message that does not lie inside it is never read -- it is hashed as the empty
+ * message and d_bad_count (device int, may be NULL) is incremented.
  * Same absorption / padding rule per message as above (CONVENTION UNPINNED: parameters, see above). */
-int hades252_sponge_hash_var_dev(const void *d_scalars, const uint64_t *d_offsets, const uint64_t *d_lengths,
-                                 size_t n_msgs, const uint64_t capacity_mont[4], int pad_mode, void *d_digests,
-                                 void *stream);
+int hades252_sponge_hash_var_dev(const void *d_scalars, size_t n_scalars, const uint64_t *d_offsets,
+                                 const uint64_t *d_lengths, size_t n_msgs, const uint64_t capacity_mont[4], int pad_mode,
+                                 void *d_digests, int *d_bad_count, void *stream);
 
 /* ---- synthetic inputs and digests (benchmark / verification plumbing) --------------------- */
 /* Generator B: scalar e (global element index first_elem + k) gets 4 splitmix64 limbs, top limb

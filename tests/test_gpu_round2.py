@@ -282,6 +282,15 @@ def test_sponge_var_equals_fixed_and_packed(torch_cuda, H, oracle):
     pool = oracle.gen_b(5, int(lens.sum()) + 1)
     got = H.sponge_hash_var(to_dev(torch, pool), to_dev(torch, offs), to_dev(torch, lens), cap, 1)
     assert (to_host(got) == oracle.sponge_var(pool, offs, lens, cap, 1)).all()
+    # a message reaching outside the pool is never read: counted, raised by the mirror
+    lens_bad = lens.copy()
+    lens_bad[7] = np.uint64(1 << 40)
+    with pytest.raises(IndexError):
+        H.sponge_hash_var(to_dev(torch, pool), to_dev(torch, offs), to_dev(torch, lens_bad), cap, 1)
+    offs_bad = offs.copy()
+    offs_bad[9] = np.uint64((1 << 64) - 3)                      # offset + length would wrap around
+    with pytest.raises(IndexError):
+        H.sponge_hash_var(to_dev(torch, pool), to_dev(torch, offs_bad), to_dev(torch, lens), cap, 1)
 
 
 # ---------------------------------------------------------------------------------------------
