@@ -95,3 +95,51 @@ def test_mds_blob_through_c_oracle_field_ops(oracle):
             # and it really is the inverse: x * x^-1 = one, through the oracle
             s = oracle.fr2("add", oracle.fr1("from_raw", i), oracle.fr1("from_raw", j + 5))
             assert oracle.fr2("mul", s, limbs[5 * i + j]) == R
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference's own constant test (src/round_constants.rs:55-65: every constant is non-zero and
+# survives to_bytes -> from_bytes), made absolute: under the loader's from_raw reading the canonical
+# bytes of ROUND_CONSTANTS[i] ARE chunk i of assets/ark.bin (and MDS_MATRIX[i][j] chunk 5i+j of
+# assets/mds.bin).  CPU twin of tests/test_gpu_round3.py::test_wire_format_pinned_to_reference_blobs.
+# ---------------------------------------------------------------------------------------------
+def blob_bytes(name):
+    """The blob, regenerated with plain integers from the documented algorithm (HOWTO.md:21-39, :71-97),
+    sha256-pinned; the reference's file itself when /root/reference is present (this container)."""
+    import hashlib as h
+    if name == "ark":
+        run, data, out = 1, b"poseidon-for-plonk", []
+        for _ in range(960):
+            data = h.sha512(data).digest()
+            run = (int.from_bytes(data, "little") + run) % P
+            out.append(run * R % P)
+        want = ARK_SHA256
+    else:
+        out = [pow(i + j + 5, -1, P) * R % P for i in range(5) for j in range(5)]
+        want = MDS_SHA256
+    blob = b"".join(v.to_bytes(32, "little") for v in out)
+    assert h.sha256(blob).hexdigest() == want
+    path = os.path.join(REF_ASSETS, name + ".bin")
+    if os.path.exists(path):
+        assert blob == open(path, "rb").read()
+    return blob
+
+
+def test_round_constants_to_bytes_from_bytes_equal_blob(oracle):
+    import numpy as np
+    ark = blob_bytes("ark")
+    for i in range(960):
+        c = np.array(limbs_of(oracle.round_constant(i)), dtype=np.uint64)
+        assert c.any()                                              # round_constants.rs:58
+        chunk = ark[32 * i:32 * i + 32]
+        assert oracle.to_bytes(c) == chunk                          # to_bytes(ROUND_CONSTANTS[i]) == file chunk i
+        rc, back = oracle.from_bytes(chunk)                         # from_bytes(...) == ROUND_CONSTANTS[i]  (:61-62)
+        assert rc == 0 and (back == c).all()
+    mds = blob_bytes("mds")
+    for i in range(5):
+        for j in range(5):
+            c = np.array(limbs_of(oracle.mds(i, j)), dtype=np.uint64)
+            chunk = mds[32 * (5 * i + j):32 * (5 * i + j) + 32]
+            assert oracle.to_bytes(c) == chunk
+            rc, back = oracle.from_bytes(chunk)
+            assert rc == 0 and (back == c).all()
