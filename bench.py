@@ -7,9 +7,9 @@
 A step is one pass of the hot path (the batched `ScalarStrategy::perm`, through the C ABI
 `hades252_perm_batch_dev`) over one synthetic batch already resident in HBM: 2^26 independent
 width-5 permutations per GPU (BASELINE.json configs[2]; 10 GiB in place), generated on device by
-the counter-based generator B.  With N GPUs every rank owns its own batch (weak scaling, global
-element indices are disjoint; at N = 8 the default is 2^27 per GPU = BASELINE.json configs[4], 2^30
-in total); there is no data-path collective.  Rank 0 prints ONE JSON line.
+the counter-based generator B.  With N GPUs every rank owns its own batch of the SAME size (weak
+scaling, global element indices are disjoint; `--perms-per-gpu 134217728` gives BASELINE.json
+configs[4], 2^30 over 8 GPUs); there is no data-path collective.  Rank 0 prints ONE JSON line.
 
 Launching: under torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this process is one
 rank.  Without it, `--gpus N` with N > 1 makes this process a LAUNCHER: it spawns N rank processes
@@ -23,8 +23,13 @@ Also in the line:
                 events on the launch stream.  `traffic` is the HBM byte count of one launch from
                 the committed rocprofv3 PMC run (profiles/), or null.
   cpu_baseline  the CPU oracle (oracle/hades_oracle.c, a port: the Rust reference cannot be
-                built in this image) timed on this host on a bounded sample of the same
+                built in this image) timed on this host (rank 0) on a bounded sample of the same
                 workload; the same sample is used to check the GPU output bit for bit.
+  secondary     outside `value`: BASELINE.json configs[3] (arity-4 Merkle tree over 2^24 leaves: tree
+                time, nodes/s, its own roofline with 160 B per node), and `host_path`: the entry point a
+                Rust `Strategy::perm` binds (`hades252_perm_batch`: host memory in, host memory out,
+                PCIe-inclusive) on 2^22 states against this box's measured bidirectional copy ceiling.
+`--workload merkle` times the tree build itself as the step (development; the driver runs the default).
 """
 from __future__ import annotations
 
@@ -49,10 +54,8 @@ PEAK_CLOCK_HZ = 2.4e9
 # Issue model: a wave64 instruction occupies its SIMD-16 for 4 cycles when 64-bit, 2 cycles when 32-bit
 # (MI355X_MICROARCH.md).  IDEAL peak = one 64-bit op per SIMD per 4 cycles at the 2.4 GHz peak clock.
 VALU_IDEAL_G_WI = N_SIMD * PEAK_CLOCK_HZ / 4 / 1e9  # 614.4 G 64-bit wave-instr/s
-# MEASURED peak: tools/ubench3.hip, pure v_mad_i64_i32 (v,s operands) stream, 8 waves/SIMD forced by an LDS pad,
-# residency verified from HW_ID, wall-clock rate == in-kernel-timestamp rate (profiles/r2/ubench3_valu_ceiling.txt:
-# 546.96 / 547.02 G wave-instr/s); = 4.4 cycles per instruction at the 2.36 GHz the counters show under this load.
-VALU_MEASURED_G_WI = 547.0
+MERKLE_BYTES_PER_NODE = 160        # 4 x 32 B children in + 32 B digest out
+COOP_MAX_STATES = 1 << 14          # hades252.hip kCoopMaxStates: DEFAULT dispatch picks the five-waves kernel up to here
 
 
 def usable_cores() -> int:
@@ -70,7 +73,7 @@ def usable_cores() -> int:
     return max(1, min(n, 256))
 
 
-def cpu_baseline_and_check(H, torch, device, n_sample: int):
+def cpu_baseline_and_check(H, torch, device, n_sample: int, kernel: int):
     """Time the CPU oracle on the first n_sample permutations of the workload and use its
     output to check the GPU path.  The oracle is used here only as baseline + checker."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -89,7 +92,7 @@ def cpu_baseline_and_check(H, torch, device, n_sample: int):
     tall = time.perf_counter() - t0
     # parity of the GPU path on the same inputs
     buf = H.gen_b(5 * n_sample, device)
-    H.ScalarStrategy().perm(buf)
+    H.ScalarStrategy(kernel).perm(buf)
     got = buf.cpu().numpy().view(np.uint64).reshape(-1)
     ok = bool((got == exp).all())
     return {
@@ -100,25 +103,30 @@ def cpu_baseline_and_check(H, torch, device, n_sample: int):
     }, ok
 
 
-def verify_sample(H, torch, states, first_perm: int, n: int, k: int) -> bool:
-    """Bit-exact check of k states of THIS rank's shard (first k/2 + k/2 strided) against the oracle.
-    Runs before the timed region on the freshly generated inputs; the oracle is the checker only."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
-    import oracle_lib
-    orc = oracle_lib.load()
-    k = max(2, min(k, n))
-    idx = np.unique(np.concatenate([np.arange(k // 2), np.arange(0, n, max(1, n // (k // 2)))[: k // 2]]))
-    tidx = torch.from_numpy(idx).to(states.device)
-    sample = states[tidx].contiguous()
-    inp = sample.cpu().numpy().view(np.uint64).reshape(-1).copy()
-    # inputs are what generator B defines for these global indices
-    e0 = 5 * (first_perm + int(idx[-1]))
-    if not (inp[-20:] == orc.gen_b(e0, 5)).all():
-        return False
-    H.ScalarStrategy().perm(sample)
-    got = sample.cpu().numpy().view(np.uint64).reshape(-1)
-    return bool((got == orc.perm_batch(inp, min(usable_cores(), 8))).all())
+class ShardCheck:
+    """Bit-exact check of THIS rank's shard against the oracle, on the very buffer and by the very launches that
+    are timed: k sampled states (first k/2 + k/2 strided) are read before the first step (inputs: they must be what
+    generator B defines) and again after the last one, and must then equal the oracle's permutation applied as many
+    times as the kernel was launched (warm-up + timed steps).  The oracle is the checker only."""
+
+    def __init__(self, torch, states, first_perm: int, n: int, k: int):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import numpy as np
+        import oracle_lib
+        self.np, self.orc, self.states = np, oracle_lib.load(), states
+        k = max(2, min(k, n))
+        idx = np.unique(np.concatenate([np.arange(k // 2), np.arange(0, n, max(1, n // (k // 2)))[: k // 2]]))
+        self.tidx = torch.from_numpy(idx).to(states.device)
+        self.inp = states[self.tidx].contiguous().cpu().numpy().view(np.uint64).reshape(-1).copy()
+        e0 = 5 * (first_perm + int(idx[-1]))
+        self.inputs_ok = bool((self.inp[-20:] == self.orc.gen_b(e0, 5)).all())
+
+    def after(self, n_applications: int) -> bool:
+        got = self.states[self.tidx].contiguous().cpu().numpy().view(self.np.uint64).reshape(-1)
+        exp = self.inp
+        for _ in range(n_applications):
+            exp = self.orc.perm_batch(exp, min(usable_cores(), 8))
+        return self.inputs_ok and bool((got == exp).all())
 
 
 def launch_ranks(args) -> int:
@@ -140,16 +148,90 @@ def launch_ranks(args) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # poll ALL ranks: if one dies (before or inside a collective) the others would wait for it until the backend's
+    # timeout -- end them instead and report the first failure
     rc = 0
     try:
-        for p in procs:
-            p.wait()
-            rc = rc or p.returncode
+        live = list(procs)
+        while live and rc == 0:
+            time.sleep(0.05)
+            for p in list(live):
+                if p.poll() is not None:
+                    live.remove(p)
+                    rc = rc or p.returncode
     finally:
         for p in procs:
             if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
                 p.kill()
+                p.wait()
     return rc
+
+
+def kernel_of(kernel_arg: int, n: int) -> str:
+    """The kernel `hades252_perm_batch_dev_ex(.., kernel)` launches for n states (same rule as the C dispatch)."""
+    from hades252_amd import _lib
+    if kernel_arg == _lib.KERNEL_LITERAL:
+        return "k_states_literal"
+    if kernel_arg == _lib.KERNEL_COOP or (kernel_arg == _lib.KERNEL_DEFAULT and n <= COOP_MAX_STATES):
+        return "k_perm_coop"
+    if kernel_arg == getattr(_lib, "KERNEL_LANES", -1):
+        return "k_perm_lanes"
+    return "k_perm_fast"
+
+
+def merkle_record(H, torch, device, log_leaves: int, reps: int = 5):
+    """BASELINE.json configs[3]: arity-4 Poseidon Merkle tree over 2^log_leaves leaves resident in HBM (generator B,
+    tag 15, digest = word 1 -- the external convention, a parameter), root only.  HIP events around each build."""
+    from hades252_amd import _lib
+    n = 1 << log_leaves
+    p_mod = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    tag = 15 * ((1 << 256) % p_mod) % p_mod
+    leaves = H.gen_b(n, device)
+    scratch = torch.empty(max(_lib.lib().hades252_merkle_scratch_bytes(n, 4) // 8, 2), dtype=torch.int64, device=device)
+    H.merkle_root(leaves, 4, tag, 1, scratch)
+    ms = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        root = H.merkle_root(leaves, 4, tag, 1, scratch)
+        b.record()
+        torch.cuda.synchronize()
+        ms.append(a.elapsed_time(b))
+    med = sorted(ms)[len(ms) // 2]
+    nodes = (n - 1) // 3
+    ach = MERKLE_BYTES_PER_NODE * nodes / (med * 1e-3) / 1e9
+    return {"workload": "arity-4 Poseidon Merkle tree over 2^%d leaves in HBM, root only (BASELINE configs[3]; tag 15, "
+                        "digest word 1: external convention, parameters)" % log_leaves,
+            "tree_ms": med, "tree_ms_all": ms, "nodes": nodes, "nodes_per_s": nodes / (med * 1e-3),
+            "root": "".join("%016x" % (int(v) & 0xFFFFFFFFFFFFFFFF) for v in reversed(root.cpu().tolist())),
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_node": MERKLE_BYTES_PER_NODE}}, leaves
+
+
+def host_path_record(log_n: int = 22):
+    """The boundary a Rust `Strategy::perm` binds: `hades252_perm_batch` on host memory (PCIe-inclusive; never
+    `value`), measured by a NATIVE caller -- tools/host_path_bench.cpp, a plain C++ program linked against the
+    system HIP runtime like a Rust / C host, started here as a child process.  (Inside this PyTorch process the
+    library runs on PyTorch's own bundled HIP runtime, under which the same copy / kernel pipeline overlaps far worse:
+    profiles/r3/host_path.txt.)  The ceiling is measured by that same program in the same run."""
+    import subprocess
+    from hades252_amd import build
+    exe = build.build_host_path_bench(verbose=False)
+    res = subprocess.run([exe, str(log_n)], capture_output=True, text=True, timeout=300)
+    if res.returncode != 0:
+        raise RuntimeError("host_path_bench failed: " + res.stderr[-500:])
+    rec = json.loads(res.stdout.strip().splitlines()[-1])
+    rec["entry_point"] = ("hades252_perm_batch on page-locked host memory from hades252_host_alloc: chunks copied in, "
+                          "permuted and copied out on three streams chained by events (native C++ caller, system HIP "
+                          "runtime)")
+    rec["ceiling"] = ("hipMemcpyAsync of the same bytes in both directions at once (20 MiB pieces, page-locked memory, "
+                      "best of 4 stream pairs), measured by the same process in this run")
+    return rec
 
 
 def main():
@@ -158,11 +240,17 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--perms-per-gpu", type=int, default=0,
-                    help="default: 2^26 (BASELINE configs[2]); 2^27 at 8 GPUs (configs[4]: 2^30 in total)")
-    ap.add_argument("--kernel", type=int, default=0, help="0 default (fast), 1 literal, 2 fast")
+                    help="default: 2^26 at every N (BASELINE configs[2]); 134217728 = configs[4] (2^30 over 8 GPUs)")
+    ap.add_argument("--kernel", type=int, default=0,
+                    help="0 default dispatch (k_perm_fast above 16384 states), 1 literal, 2 fast, 3 coop (five waves "
+                         "per state), 4 lanes (lane-split low latency)")
+    ap.add_argument("--workload", default="perm", choices=["perm", "merkle"],
+                    help="perm: the headline (BASELINE configs[2]); merkle: a step = one arity-4 tree build over "
+                         "2^24 leaves (configs[3]; development -- the default run reports it under `secondary`)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 20)
     ap.add_argument("--verify-sample", type=int, default=2048, help="states per rank checked against the oracle (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the Merkle / host-path records")
     # test hooks for boxes with fewer GPUs than ranks (control-flow check of the N>1 path only)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (testing)")
@@ -172,7 +260,7 @@ def main():
         raise SystemExit(launch_ranks(args))
 
     import torch
-    from hades252_amd import build, sharding
+    from hades252_amd import build, sharding, _lib
     build.build(verbose=False)
     from hades252_amd import strategy as H
 
@@ -186,14 +274,16 @@ def main():
     if world > 1:
         sharding.init_process_group(args.dist_backend)
 
-    n = args.perms_per_gpu or ((1 << 27) if world == 8 else (1 << 26))
+    if args.workload == "merkle":
+        return bench_merkle(args, H, torch, device, sharding, rank, world)
+
+    n = args.perms_per_gpu or (1 << 26)
+    kernel_name = kernel_of(args.kernel, n)
     first_perm, _ = sharding.weak_shard(rank, n)
     strat = H.ScalarStrategy(args.kernel)
     states = torch.empty((n, 5, 4), dtype=torch.int64, device=device)
     H.gen_b(5 * n, device, first_elem=5 * first_perm, out=states.view(-1, 4))
-    rank_ok = True
-    if world > 1:
-        rank_ok = verify_sample(H, torch, states, first_perm, n, args.verify_sample)
+    check = ShardCheck(torch, states, first_perm, n, args.verify_sample)
 
     for _ in range(args.warmup):
         strat.perm(states)
@@ -215,6 +305,8 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
     kernel_ms_max = sharding.reduce_max(kernel_ms, device)
     per_rank_ms = sharding.gather_floats(kernel_ms, device)
+    # the timed launches themselves, checked on every rank: sampled states after warm-up + timed steps
+    rank_ok = check.after(args.warmup + args.steps)
     all_ok = sharding.reduce_min_int(1 if rank_ok else 0, device) == 1
     digest = sharding.combine_digests(H.digest(states, first_index=20 * first_perm), device)
 
@@ -222,12 +314,14 @@ def main():
         if not rank_ok:
             raise SystemExit("rank %d: GPU output differs from the CPU oracle" % rank)
         return
+    del states
+    torch.cuda.empty_cache()
     total_perms = n * world * args.steps
     value = total_perms / elapsed
     achieved = ALGO_BYTES_PER_PERM * n / (kernel_ms_max * 1e-3) / 1e9
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
+    if kernel_name == "k_perm_fast" and os.path.exists(tpath):
         try:
             rec = json.load(open(tpath))
             if rec.get("perms_per_launch") == n and rec.get("kernel_source_hash") == build.perm_fast_hash():
@@ -247,40 +341,65 @@ def main():
                                 % (n.bit_length() - 1, "configs[4]: 2^30 over 8 GPUs" if (world == 8 and n == 1 << 27)
                                    else "configs[2]")) if pow2 else "%d permutations per GPU" % n,
                    "perms_per_gpu": n, "total_perms_per_step": n * world, "state_bytes": 160,
-                   "kernel": "k_perm_fast" if args.kernel != 1 else "k_states_literal",
+                   "kernel": kernel_name,
                    "sharding": "contiguous range per rank, no collective"},
         "per_gpu": {"value": value / world, "unit": "permutations/s",
                     "kernel_ms_per_rank": per_rank_ms,
                     "perms_per_s_per_rank": [n / (ms * 1e-3) for ms in per_rank_ms]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel_ms": kernel_ms_max, "algorithmic_bytes_per_perm": ALGO_BYTES_PER_PERM,
+                     "kernel": kernel_name, "kernel_ms": kernel_ms_max,
+                     "algorithmic_bytes_per_perm": ALGO_BYTES_PER_PERM,
                      "note": "HBM traffic equals the algorithmic bytes; the kernel is VALU-issue bound "
                              "(~89 k instructions per 320 B), see valu_issue and DESIGN.md"},
-        "valu_issue": (lambda eq: {
+        "digest": ["%016x" % d for d in digest],
+        "parity_vs_cpu_sample": all_ok,
+        "parity_sample": "%d states of every rank's shard, read back after the %d timed + warm-up launches of the timed "
+                         "kernel and compared with the CPU oracle applied as many times; AND over ranks"
+                         % (args.verify_sample, args.warmup + args.steps),
+    }
+    if kernel_name == "k_perm_fast":
+        eq = (OPS64_PER_PERM + 0.5 * OPS32_PER_PERM) * n / (kernel_ms_max * 1e-3) / 64 / 1e9
+        out["valu_issue"] = {
             "bound": "VALU issue: 64-bit integer multiply-add pipe (the binding bound; HBM idles at 1.7 %)",
             "achieved": eq, "unit": "G 64-bit-equivalent wave-instr/s",
             "peak": VALU_IDEAL_G_WI, "frac": eq / VALU_IDEAL_G_WI,
-            "peak_measured": VALU_MEASURED_G_WI, "frac_of_measured": eq / VALU_MEASURED_G_WI,
             "mads_per_perm": MADS_PER_PERM, "ops64_per_perm": OPS64_PER_PERM, "ops32_per_perm": OPS32_PER_PERM,
             "note": "achieved = (64-bit ops + 0.5 x 32-bit ops) per permutation x permutations/s / 64 lanes; peak = 1024 "
-                    "SIMDs x 2.4 GHz / 4 cycles (ideal pipe); peak_measured = sustained pure v_mad_i64_i32 stream at 8 "
-                    "waves/SIMD (tools/ubench3.hip, profiles/r2/): the kernel runs at the rate the pipe sustains, "
-                    "only fewer instructions can make it faster"})(
-            (OPS64_PER_PERM + 0.5 * OPS32_PER_PERM) * n / (kernel_ms_max * 1e-3) / 64 / 1e9),
-        "digest": ["%016x" % d for d in digest],
-    }
-    if world > 1:
-        out["parity_vs_cpu_sample"] = all_ok
-        out["parity_sample"] = "%d states of every rank's shard vs the CPU oracle, AND over ranks" % args.verify_sample
-    if world == 1 and not args.no_cpu_baseline:
-        cb, ok = cpu_baseline_and_check(H, torch, device, args.cpu_sample)
+                    "SIMDs x 2.4 GHz / 4 cycles (ideal pipe at the peak clock); only fewer instructions can make the "
+                    "kernel faster (DESIGN.md section 5)"}
+    if not args.no_cpu_baseline:
+        cb, ok = cpu_baseline_and_check(H, torch, device, args.cpu_sample, args.kernel or _lib.KERNEL_FAST)
         out["cpu_baseline"] = cb
-        out["parity_vs_cpu_sample"] = ok
-        all_ok = ok
+        out["parity_vs_cpu_sample"] = all_ok = all_ok and ok
+    if not args.no_secondary:
+        sec = {}
+        try:
+            sec["merkle_2p24"], leaves = merkle_record(H, torch, device, 24)
+            del leaves
+            torch.cuda.empty_cache()
+            sec["host_path"] = host_path_record(22)
+        except Exception as e:                       # secondary records never take the headline down
+            sec["error"] = repr(e)
+        out["secondary"] = sec
     print(json.dumps(out), flush=True)
     if not all_ok:
         raise SystemExit("GPU output differs from the CPU oracle")
+
+
+def bench_merkle(args, H, torch, device, sharding, rank, world):
+    """--workload merkle: a step = one tree build (root only) over 2^24 leaves per GPU, every rank its own tree."""
+    rec, leaves = merkle_record(H, torch, device, 24, reps=max(1, args.steps))
+    ms = sharding.reduce_max(rec["tree_ms"], device)
+    if rank != 0:
+        return
+    nodes = rec["nodes"]
+    out = {"metric": "Poseidon Merkle tree nodes/sec (arity 4, 2^24 leaves; Hades252 WIDTH=5)",
+           "value": nodes * world / (ms * 1e-3), "unit": "nodes/s", "n_gpus": world, "steps": args.steps,
+           "warmup": 1, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "int64", "data": "synthetic", "config": {"workload": rec["workload"]},
+           "roofline": rec["roofline"], "root": rec["root"]}
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

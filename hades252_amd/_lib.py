@@ -22,6 +22,7 @@ KERNEL_DEFAULT = 0
 KERNEL_LITERAL = 1
 KERNEL_FAST = 2
 KERNEL_COOP = 3
+MULTI_VIRTUAL = 1
 
 # every symbol include/hades252.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -35,6 +36,12 @@ SIGNATURES = {
     "hades252_perm_batch_dev": (c_int, [c_void_p, c_size_t, c_void_p]),
     "hades252_perm_batch_dev_ex": (c_int, [c_void_p, c_size_t, c_void_p, c_int]),
     "hades252_perm_batch_multi": (c_int, [c_void_p, c_size_t, c_int]),
+    "hades252_perm_batch_multi_ex": (c_int, [c_void_p, c_size_t, c_int, ctypes.c_uint]),
+    "hades252_host_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "hades252_host_free": (c_int, [c_void_p]),
+    "hades252_host_register": (c_int, [c_void_p, c_size_t]),
+    "hades252_host_unregister": (c_int, [c_void_p]),
+    "hades252_host_is_pinned": (c_int, [c_void_p, c_size_t]),
     "hades252_perm_trace_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "hades252_perm_trace_dev_ex": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
     "hades252_witness_wires": (c_int, []),

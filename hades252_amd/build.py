@@ -22,10 +22,10 @@ LIB = os.path.join(CSRC, "libhades252.so")
 STAMP = LIB + ".stamp"
 LOCK = LIB + ".lock"
 SOURCES = ["hades252.hip"]
-DEPS = ["hades252.hip", "fr32.cuh", "staging.cuh", "hades_literal.cuh", "hades_fast.cuh", "hades_coop.cuh",
+DEPS = ["hades252.hip", "fr32.cuh", "staging.cuh", "hades_literal.cuh", "hades_fast.cuh", "k_perm_fast.cuh", "hades_coop.cuh",
         "hades_constants.inc", os.path.join("..", "..", "include", "hades252.h")]
 # what the dominant kernel (k_perm_fast) is made of: profiles recorded for it stay valid while these are unchanged
-PERM_FAST_DEPS = ["fr32.cuh", "staging.cuh", "hades_fast.cuh"]
+PERM_FAST_DEPS = ["fr32.cuh", "staging.cuh", "hades_fast.cuh", "k_perm_fast.cuh"]
 # ... plus these tables of hades_constants.inc (other kernels' tables may change without touching k_perm_fast)
 PERM_FAST_TABLES = ("HADES_FAST_L", "HADES_FAST_MDS_SMALL", "HADES_NEG_P29", "HADES_TWO_P29", "HADES_FAST_ROUND_INIT",
                     "HADES_FAST_FINAL_F")
@@ -89,6 +89,43 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+# ---- native measurement tool of the host-pointer boundary (tools/host_path_bench.cpp) -------------------------
+# A plain C++ caller of the C ABI, linked against the SYSTEM HIP runtime like a Rust / C host would be (a PyTorch
+# process loads PyTorch's own bundled runtime, under which the same pipeline overlaps its copies far worse).
+ROOT = os.path.dirname(os.path.dirname(CSRC))
+TOOL_SRC = os.path.join(ROOT, "tools", "host_path_bench.cpp")
+TOOL_BIN = os.path.join(ROOT, "build_tools", "host_path_bench")
+
+
+def build_host_path_bench(verbose: bool = True) -> str:
+    build(verbose=verbose)
+    h = hashlib.sha256()
+    for f in (TOOL_SRC, os.path.join(ROOT, "include", "hades252.h")):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    want = h.hexdigest()
+    stamp = TOOL_BIN + ".stamp"
+    os.makedirs(os.path.dirname(TOOL_BIN), exist_ok=True)
+    if os.path.exists(TOOL_BIN) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return TOOL_BIN
+    with open(LOCK, "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            tmp = TOOL_BIN + ".tmp.%d" % os.getpid()
+            cmd = [HIPCC, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", tmp, TOOL_SRC, "-L" + CSRC,
+                   "-lhades252", "-Wl,-rpath,$ORIGIN/../hades252_amd/csrc"]
+            if verbose:
+                print("[hades252_amd.build]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, TOOL_BIN)
+            with open(stamp, "w") as f:
+                f.write(want + "\n")
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return TOOL_BIN
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_host_path_bench()
     print(LIB)

@@ -15,6 +15,7 @@
 #include "hades_literal.cuh"
 #include "staging.cuh"
 #include "hades_fast.cuh"
+#include "k_perm_fast.cuh"
 #include "hades_coop.cuh"
 
 using namespace hades;
@@ -30,7 +31,7 @@ __device__ const uint32_t d_mds_mont[25][8] = HADES_MDS_MONT_INIT;
 __device__ const uint32_t d_r2[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu,
                                      0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
 
-__device__ const FastTables d_fast = {HADES_FAST_ROUND_INIT, HADES_FAST_FINAL_F};
+// d_fast (the throughput kernel's round records) is defined next to its kernel in k_perm_fast.cuh
 // low-latency schedule (hades_coop.cuh)
 __device__ const CoopTables d_coop = {HADES_COOP_ROUND_INIT, HADES_COOP_FINAL_F, HADES_FAST_MDS_SMALL};
 // trace kernel: U_r with mont(X_after_round_r, U_r) = x * 2^256
@@ -54,17 +55,9 @@ __device__ const int32_t d_rp_times_r[16] = HADES_RP_TIMES_R29;
 __device__ const int32_t d_rp_over_r[16] = HADES_RP_OVER_R29;
 __device__ const int32_t d_rp2_over_r[16] = HADES_RP2_OVER_R29;
 
-constexpr int kBlock = 256;
-constexpr int kWavesPerBlock = kBlock / kWave;
-
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
-template <int NW>
-__device__ __forceinline__ uint8_t *wave_slab(uint8_t *lds) {
-    return lds + (threadIdx.x / kWave) * lds_wave_bytes(NW);
-}
-
 enum Op { OP_PERM = 0, OP_ARK, OP_MDS, OP_FULL, OP_PARTIAL };
 
 // st[4] <- st[3] <- ... <- st[0] <- st[4]: loops over the five words rotate the state through ONE code body
@@ -369,23 +362,6 @@ __global__ void __launch_bounds__(kBlock) k_wire(const uint8_t *in, uint8_t *out
         q[0] = make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]);
         q[1] = make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]);
     }
-}
-
-// The shipped hot path: one permutation per lane, scale-tracked formulation (hades_fast.cuh).
-// __launch_bounds__(256, 4): 4 waves per SIMD = at most 128 VGPRs; the kernel needs 108 and does
-// not spill.  (2 waves/SIMD: same speed; 5: spills, 6 % slower; 6: 35 % slower -- measured.)
-#ifndef HADES_FAST_MINW
-#define HADES_FAST_MINW 4
-#endif
-__global__ void __launch_bounds__(kBlock, HADES_FAST_MINW) k_perm_fast(uint8_t *states, size_t n) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t *slab = wave_slab<5>(lds);
-    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
-    Fr st[5];
-    wave_load_records<5>(states, rec0, n, slab, st);
-    Fr out[5];
-    fast_perm<5>(&d_fast, st, out, 0);
-    wave_store_records<5>(states, rec0, n, slab, out);
 }
 
 // One Merkle level, one parent per lane: parent = perm([tag, c_0 .. c_{ARITY-1}, 0 ..])[out_idx]
@@ -748,8 +724,8 @@ static inline unsigned blocks_for(size_t n) { return (unsigned)((n + kBlock - 1)
 static inline size_t lds_for(int nw) { return (size_t)kWavesPerBlock * lds_wave_bytes(nw); }
 static constexpr size_t kMaxLaunchRecords = (size_t)1 << 30;   // grid.x * 256 per launch
 
-static int launch_perm_fast(uint8_t *states, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_perm_fast, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, states, n);
+static int launch_perm_fast(const uint8_t *in, uint8_t *out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_perm_fast, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, in, out, n);
     return HADES252_OK;
 }
 static Fr fr_from_u64(const uint64_t v[4]) {
@@ -844,7 +820,7 @@ int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int
             hipLaunchKernelGGL(k_states_literal<OP_PERM>, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s,
                                p + off * 160, n, 0);
         } else if (kernel == HADES252_KERNEL_FAST) {
-            int rc = launch_perm_fast(p + off * 160, n, s);
+            int rc = launch_perm_fast(p + off * 160, p + off * 160, n, s);
             if (rc != HADES252_OK) return rc;
         } else {
             return HADES252_ERR_INVALID_ARG;
@@ -858,16 +834,106 @@ int hades252_perm_batch_dev(void *d_states, size_t n_perms, void *stream) {
     return hades252_perm_batch_dev_ex(d_states, n_perms, stream, HADES252_KERNEL_DEFAULT);
 }
 
+// ---- page-locked host memory --------------------------------------------------------------------
+// The reference's caller owns a `&mut [BlsScalar]` in ordinary (pageable) memory (src/strategies.rs:140).  DMA needs
+// page-locked memory; locking and unlocking the caller's buffer on every call costs more than the transfer itself
+// for mid-sized batches.  A caller that keeps its states in one long-lived buffer therefore pins it ONCE, either by
+// allocating it here (hades252_host_alloc) or by registering its own allocation (hades252_host_register); the
+// host-pointer entry points recognise such memory and go straight to DMA.  Per-call registration stays as the
+// fallback for everything else.
+struct PinnedRange {
+    uintptr_t lo, hi;
+    bool owned;                 // allocated by hades252_host_alloc (freed by hades252_host_free)
+};
+static std::mutex g_pin_mu;
+static std::vector<PinnedRange> g_pins;
+
+int hades252_host_alloc(void **out, size_t bytes) {
+    if (out == nullptr || bytes == 0) return HADES252_ERR_INVALID_ARG;
+    *out = nullptr;
+    int rc = check_device();
+    if (rc != HADES252_OK) return rc;
+    void *p = nullptr;
+    // portable: page-locked for every device (hades252_perm_batch_multi); mapped: kernels may access it directly
+    HIP_TRY(hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped));
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        g_pins.push_back({(uintptr_t)p, (uintptr_t)p + bytes, true});
+    }
+    *out = p;
+    return HADES252_OK;
+}
+
+static int forget_range(void *p, bool owned) {       // 1 = found and removed
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (size_t i = 0; i < g_pins.size(); i++)
+        if (g_pins[i].lo == (uintptr_t)p && g_pins[i].owned == owned) {
+            g_pins.erase(g_pins.begin() + i);
+            return 1;
+        }
+    return 0;
+}
+
+int hades252_host_free(void *p) {
+    if (p == nullptr) return HADES252_OK;
+    if (!forget_range(p, true)) return HADES252_ERR_INVALID_ARG;       // not from hades252_host_alloc
+    HIP_TRY(hipHostFree(p));
+    return HADES252_OK;
+}
+
+int hades252_host_register(void *p, size_t bytes) {
+    if (p == nullptr || bytes == 0) return HADES252_ERR_INVALID_ARG;
+    int rc = check_device();
+    if (rc != HADES252_OK) return rc;
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pins.push_back({(uintptr_t)p, (uintptr_t)p + bytes, false});
+    return HADES252_OK;
+}
+
+int hades252_host_unregister(void *p) {
+    if (p == nullptr) return HADES252_OK;
+    if (!forget_range(p, false)) return HADES252_ERR_INVALID_ARG;      // not registered through this library
+    HIP_TRY(hipHostUnregister(p));
+    return HADES252_OK;
+}
+
+// is [p, p + bytes) page-locked already?  First the ranges this library handed out or registered, then the
+// runtime's own view (memory the caller pinned with hipHostMalloc / hipHostRegister directly).
+static bool host_range_pinned(const void *p, size_t bytes) {
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (const PinnedRange &r : g_pins)
+            if (lo >= r.lo && hi <= r.hi) return true;
+    }
+    hipPointerAttribute_t a0, a1;
+    if (hipPointerGetAttributes(&a0, p) != hipSuccess ||
+        hipPointerGetAttributes(&a1, (const uint8_t *)p + (bytes - 1)) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a0.type == hipMemoryTypeHost && a1.type == hipMemoryTypeHost;
+}
+
+int hades252_host_is_pinned(const void *p, size_t bytes) {
+    if (p == nullptr || bytes == 0) return 0;
+    return host_range_pinned(p, bytes) ? 1 : 0;
+}
+
 // ---- host-pointer path ------------------------------------------------------------------------
-// A small pool of (stream, device buffer) slots so that a call does not pay hipMalloc / hipFree /
-// hipStreamCreate (about 1 ms together) every time -- the reference's callers issue many small
-// calls.  Slots are created on demand, handed out exclusively and returned; the pool is bounded by
-// the peak number of concurrent calls (x2 for chunked batches) and by 40 MiB per slot.
-struct HostSlot {
+// A pooled "pipe" per concurrent host call: three streams (host->device copies, kernels, device->host copies),
+// kPipeSlots chunk buffers in device memory and the events that chain them, so that a call pays neither hipMalloc /
+// hipFree nor stream / event creation (about 1 ms together) -- the reference's callers issue many small calls.
+// Pipes are created on demand, handed out exclusively and returned; the pool is bounded by the peak number of
+// concurrent calls and by kPipeSlots x 40 MiB of device memory per pipe.
+constexpr int kPipeSlots = 6;
+struct HostPipe {
     int device = -1;
-    hipStream_t stream = nullptr;
-    void *buf = nullptr;
-    size_t cap = 0;
+    hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
+    void *buf = nullptr;          // kPipeSlots slots of slot_cap bytes
+    size_t slot_cap = 0;
+    hipEvent_t in_done[kPipeSlots] = {}, k_done[kPipeSlots] = {}, out_done[kPipeSlots] = {};
     void *pinned = nullptr;       // small-call staging: page-locked host memory the kernels access directly
     void *pinned_dev = nullptr;   // ... and its device-side address
 };
@@ -875,87 +941,137 @@ struct HostSlot {
 // page-locked buffer that the kernel reads and writes over PCIe itself -- one launch + one synchronisation.
 static constexpr size_t kPinnedStates = 256;
 static std::mutex g_pool_mu;
-static std::vector<HostSlot> g_pool;
+static std::vector<HostPipe> g_pool;
 
-static void release_slot(const HostSlot &s);
+static void destroy_pipe(HostPipe &p) {
+    if (p.pinned) (void)hipHostFree(p.pinned);
+    if (p.buf) (void)hipFree(p.buf);
+    for (int i = 0; i < kPipeSlots; i++) {
+        if (p.in_done[i]) (void)hipEventDestroy(p.in_done[i]);
+        if (p.k_done[i]) (void)hipEventDestroy(p.k_done[i]);
+        if (p.out_done[i]) (void)hipEventDestroy(p.out_done[i]);
+    }
+    if (p.s_in) (void)hipStreamDestroy(p.s_in);
+    if (p.s_k) (void)hipStreamDestroy(p.s_k);
+    if (p.s_out) (void)hipStreamDestroy(p.s_out);
+    (void)hipGetLastError();
+    p = HostPipe();
+}
 
-static int acquire_slot(size_t bytes, HostSlot &out) {
+static void release_pipe(const HostPipe &p) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.push_back(p);
+}
+
+// slot_bytes == 0: a small call (needs the page-locked staging buffer, no device buffer)
+static int acquire_pipe(size_t slot_bytes, HostPipe &out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    HostSlot s;
+    HostPipe p;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         int best = -1;
         for (int i = 0; i < (int)g_pool.size(); i++) {
             if (g_pool[i].device != dev) continue;
-            if (best < 0 || (g_pool[best].cap < bytes && g_pool[i].cap > g_pool[best].cap)) best = i;
-            if (g_pool[best].cap >= bytes) break;
+            if (best < 0) {
+                best = i;
+            } else if (slot_bytes == 0) {
+                // small call: a pipe that already has its staging buffer, and the smallest device buffer among those
+                // (big buffers stay available to concurrent large calls)
+                const bool bp = g_pool[best].pinned != nullptr, ip = g_pool[i].pinned != nullptr;
+                if ((ip && !bp) || (ip == bp && g_pool[i].slot_cap < g_pool[best].slot_cap)) best = i;
+            } else {
+                // large call: the smallest buffer that fits, else the largest
+                const size_t bc = g_pool[best].slot_cap, ic = g_pool[i].slot_cap;
+                if (bc >= slot_bytes ? (ic >= slot_bytes && ic < bc) : ic > bc) best = i;
+            }
         }
         if (best >= 0) {
-            s = g_pool[best];
+            p = g_pool[best];
             g_pool.erase(g_pool.begin() + best);
         }
     }
-    if (s.device < 0) {
-        s.device = dev;
-        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    }
-    if (bytes == 0 && s.pinned == nullptr) {           // small-call slot: page-locked staging instead
-        hipError_t e = hipHostMalloc(&s.pinned, kPinnedStates * 160, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipHostGetDevicePointer(&s.pinned_dev, s.pinned, 0);
-        if (e != hipSuccess) {
-            tl_last_hip_error = (int)e;
-            (void)hipGetLastError();
-            release_slot(s);
-            return HADES252_ERR_HIP;
+    auto fail = [&](hipError_t e) {
+        tl_last_hip_error = (int)e;
+        (void)hipGetLastError();
+        destroy_pipe(p);                       // nothing half-built ever returns to the pool
+        return HADES252_ERR_HIP;
+    };
+    hipError_t e = hipSuccess;
+    if (p.device < 0) {
+        p.device = dev;
+        if ((e = hipStreamCreateWithFlags(&p.s_in, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+        if ((e = hipStreamCreateWithFlags(&p.s_k, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+        if ((e = hipStreamCreateWithFlags(&p.s_out, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+        for (int i = 0; i < kPipeSlots; i++) {
+            if ((e = hipEventCreateWithFlags(&p.in_done[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
+            if ((e = hipEventCreateWithFlags(&p.k_done[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
+            if ((e = hipEventCreateWithFlags(&p.out_done[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
         }
     }
-    if (s.cap < bytes) {
-        if (s.buf) (void)hipFree(s.buf);
-        s.buf = nullptr;
-        s.cap = 0;
-        hipError_t e = hipMalloc(&s.buf, bytes);
-        if (e != hipSuccess) {
-            tl_last_hip_error = (int)e;
-            (void)hipGetLastError();
-            (void)hipStreamDestroy(s.stream);
-            return HADES252_ERR_HIP;
-        }
-        s.cap = bytes;
+    if (slot_bytes == 0 && p.pinned_dev == nullptr) {
+        if (p.pinned) (void)hipHostFree(p.pinned);
+        p.pinned = nullptr;
+        if ((e = hipHostMalloc(&p.pinned, kPinnedStates * 160, hipHostMallocMapped)) != hipSuccess) return fail(e);
+        if ((e = hipHostGetDevicePointer(&p.pinned_dev, p.pinned, 0)) != hipSuccess) return fail(e);
     }
-    out = s;
+    if (p.slot_cap < slot_bytes) {
+        if (p.buf) (void)hipFree(p.buf);
+        p.buf = nullptr;
+        p.slot_cap = 0;
+        if ((e = hipMalloc(&p.buf, slot_bytes * kPipeSlots)) != hipSuccess) return fail(e);
+        p.slot_cap = slot_bytes;
+    }
+    out = p;
     return HADES252_OK;
 }
 
-static void release_slot(const HostSlot &s) {
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_pool.push_back(s);
+static size_t host_chunk_states(size_t n_perms) {
+    // Chunks small enough that the exposed first copy-in and last copy-out are a small part of the call (about 32
+    // chunks), large enough that a chunk's kernel is a full-rate launch (>= 2^16 states) and at most 40 MiB.
+    static const size_t forced = []() -> size_t {
+        const char *e = getenv("HADES252_HOST_CHUNK");
+        return e ? (size_t)strtoull(e, nullptr, 0) : 0;
+    }();
+    if (forced) return forced;
+    size_t c = (size_t)1 << 16;
+    while (c < ((size_t)1 << 18) && c * 32 < n_perms) c <<= 1;
+    return c;
 }
 
-// Host batch on the current device: chunked, double-buffered H2D / kernel / D2H on two streams.
-// `bytes_format` inputs have already been validated (all < p).
+// Host batch on the current device.  `bytes_format` inputs have already been validated (all < p).
+//   n <= 256           the kernel works on a page-locked staging buffer over PCIe (no DMA copy at all)
+//   one chunk          copy in, kernel, copy out on one stream
+//   several chunks     three streams chained by events over kPipeSlots chunk buffers: chunk c+1 travels to the device
+//                      and chunk c-1 back to the host (PCIe is full duplex) while chunk c is being permuted.  Memory the
+//                      caller has not page-locked is locked here for the duration of the call when it can be.
+// Roads not taken, measured on this pool (tools/host_pipe_probe.hip, profiles/r3/host_path.txt): a copy-out KERNEL
+// storing into the caller's memory doubles the duration of the permutation kernel running beside it and slows the
+// copy-in (its posted writes clog the fabric queues): 27-34 GB/s each way at any grid size; the permutation kernel
+// storing its results over PCIe itself runs every chunk in lockstep (compute, then a burst of stores): 29-37 GB/s;
+// DMA both ways: 43.6 GB/s = 92 % of the 47.4 GB/s the link gives bare copies in both directions at once.
 static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, bool bytes_format,
-                                             bool already_registered = false) {
+                                             bool assume_pinned = false) {
     if (n_perms == 0) return HADES252_OK;
     if (states == nullptr) return HADES252_ERR_INVALID_ARG;
     int rc = check_device();
     if (rc != HADES252_OK) return rc;
+    auto run_kernels = [&](void *d, size_t n, hipStream_t st) {
+        if (!bytes_format) return hades252_perm_batch_dev(d, n, st);
+        int r = hades252_from_bytes_dev(d, d, n * 5, nullptr, st);
+        if (r == HADES252_OK) r = hades252_perm_batch_dev(d, n, st);
+        if (r == HADES252_OK) r = hades252_to_bytes_dev(d, d, n * 5, st);
+        return r;
+    };
+    HostPipe pipe;
     if (n_perms <= kPinnedStates) {
-        HostSlot sl;
-        rc = acquire_slot(0, sl);
+        rc = acquire_pipe(0, pipe);
         if (rc != HADES252_OK) return rc;
-        memcpy(sl.pinned, states, n_perms * 160);
-        void *d = sl.pinned_dev;
-        if (bytes_format) {
-            rc = hades252_from_bytes_dev(d, d, n_perms * 5, nullptr, sl.stream);
-            if (rc == HADES252_OK) rc = hades252_perm_batch_dev(d, n_perms, sl.stream);
-            if (rc == HADES252_OK) rc = hades252_to_bytes_dev(d, d, n_perms * 5, sl.stream);
-        } else {
-            rc = hades252_perm_batch_dev(d, n_perms, sl.stream);
-        }
-        hipError_t e = hipStreamSynchronize(sl.stream);
-        if (rc == HADES252_OK && e == hipSuccess) memcpy(states, sl.pinned, n_perms * 160);
-        release_slot(sl);                                   // only now: the staging buffer belongs to the slot
+        memcpy(pipe.pinned, states, n_perms * 160);
+        rc = run_kernels(pipe.pinned_dev, n_perms, pipe.s_k);
+        hipError_t e = hipStreamSynchronize(pipe.s_k);
+        if (rc == HADES252_OK && e == hipSuccess) memcpy(states, pipe.pinned, n_perms * 160);
+        release_pipe(pipe);                                 // only now: the staging buffer belongs to the pipe
         if (rc != HADES252_OK) return rc;
         if (e != hipSuccess) {
             tl_last_hip_error = (int)e;
@@ -964,35 +1080,29 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
         }
         return HADES252_OK;
     }
-    const size_t kChunk = (size_t)1 << 18;                // 40 MiB of states per chunk
-    const size_t chunk = n_perms < kChunk ? n_perms : kChunk;
-    const int nbuf = n_perms > chunk ? 2 : 1;
+    const size_t chunk = n_perms < host_chunk_states(n_perms) ? n_perms : host_chunk_states(n_perms);
+    const size_t n_chunks = (n_perms + chunk - 1) / chunk;
     uint8_t *h = (uint8_t *)states;
-    HostSlot slot[2];
-    int have = 0;
+    rc = acquire_pipe(chunk * 160, pipe);
+    if (rc != HADES252_OK) return rc;
     bool registered = false;
     auto finish = [&](int code) {
-        for (int i = 0; i < have; i++) {
-            (void)hipStreamSynchronize(slot[i].stream);
-            release_slot(slot[i]);
-        }
+        (void)hipStreamSynchronize(pipe.s_in);
+        (void)hipStreamSynchronize(pipe.s_k);
+        (void)hipStreamSynchronize(pipe.s_out);
+        (void)hipGetLastError();
+        release_pipe(pipe);
         if (registered) (void)hipHostUnregister(h);
         return code;
     };
-    for (int i = 0; i < nbuf; i++) {
-        rc = acquire_slot(chunk * 160, slot[i]);
-        if (rc != HADES252_OK) return finish(rc);
-        have++;
-    }
-    // Large batches: page-lock the caller's buffer in place for the duration of the call, so the
-    // chunk copies are true DMA and overlap with the kernels (pageable copies are staged by the
-    // runtime at ~15 GB/s).  If registration is refused (e.g. the range is already registered by
-    // the caller) the pageable path is used; HADES252_HOST_PIN=0 disables the attempt.
+    // Memory the caller has not pinned: page-lock it in place for the duration of the call, so the chunk copies are true
+    // DMA and overlap with the kernels (pageable copies are staged by the runtime at ~15 GB/s).  If registration is
+    // refused the pageable path is used; HADES252_HOST_PIN=0 disables the attempt.
     static const bool pin_enabled = []() {
         const char *e = getenv("HADES252_HOST_PIN");
         return !(e && e[0] == '0');
     }();
-    if (pin_enabled && !already_registered && n_perms * 160 >= ((size_t)8 << 20)) {
+    if (!assume_pinned && pin_enabled && n_perms * 160 >= ((size_t)8 << 20) && !host_range_pinned(h, n_perms * 160)) {
         if (hipHostRegister(h, n_perms * 160, hipHostRegisterDefault) == hipSuccess)
             registered = true;
         else
@@ -1007,23 +1117,36 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
             return finish(HADES252_ERR_HIP);         \
         }                                            \
     } while (0)
-    int k = 0;
-    for (size_t off = 0; off < n_perms; off += chunk, k ^= (nbuf - 1)) {
-        size_t n = n_perms - off < chunk ? n_perms - off : chunk;
-        void *d = slot[k].buf;
-        hipStream_t st = slot[k].stream;
-        TRY_FIN(hipMemcpyAsync(d, h + off * 160, n * 160, hipMemcpyHostToDevice, st));
-        if (bytes_format) {
-            rc = hades252_from_bytes_dev(d, d, n * 5, nullptr, st);
-            if (rc == HADES252_OK) rc = hades252_perm_batch_dev(d, n, st);
-            if (rc == HADES252_OK) rc = hades252_to_bytes_dev(d, d, n * 5, st);
-        } else {
-            rc = hades252_perm_batch_dev(d, n, st);
-        }
+    if (n_chunks == 1) {
+        TRY_FIN(hipMemcpyAsync(pipe.buf, h, n_perms * 160, hipMemcpyHostToDevice, pipe.s_k));
+        rc = run_kernels(pipe.buf, n_perms, pipe.s_k);
         if (rc != HADES252_OK) return finish(rc);
-        TRY_FIN(hipMemcpyAsync(h + off * 160, d, n * 160, hipMemcpyDeviceToHost, st));
+        TRY_FIN(hipMemcpyAsync(h, pipe.buf, n_perms * 160, hipMemcpyDeviceToHost, pipe.s_k));
+        TRY_FIN(hipStreamSynchronize(pipe.s_k));
+        return finish(HADES252_OK);
     }
-    for (int i = 0; i < have; i++) TRY_FIN(hipStreamSynchronize(slot[i].stream));
+    // The host runs at most kPipeSlots chunks ahead of the device: it waits for the chunk that last used a slot before
+    // enqueuing the next one into it.  (A deep backlog of copies, kernels and event waits degrades the overlap --
+    // measured: 128 chunks enqueued at once run at a third of the rate of 32.  The link is the bottleneck and has
+    // kPipeSlots - 1 chunks queued while the host sleeps, so the wake-up latency is hidden.)
+    for (size_t c = 0; c < n_chunks; c++) {
+        const int k = (int)(c % kPipeSlots);
+        const size_t off = c * chunk, n = n_perms - off < chunk ? n_perms - off : chunk;
+        void *d = (uint8_t *)pipe.buf + (size_t)k * pipe.slot_cap;
+        if (c >= (size_t)kPipeSlots) TRY_FIN(hipEventSynchronize(pipe.out_done[k]));   // chunk c - kPipeSlots left slot k
+        TRY_FIN(hipMemcpyAsync(d, h + off * 160, n * 160, hipMemcpyHostToDevice, pipe.s_in));
+        TRY_FIN(hipEventRecord(pipe.in_done[k], pipe.s_in));
+        TRY_FIN(hipStreamWaitEvent(pipe.s_k, pipe.in_done[k], 0));
+        rc = run_kernels(d, n, pipe.s_k);
+        if (rc != HADES252_OK) return finish(rc);
+        TRY_FIN(hipEventRecord(pipe.k_done[k], pipe.s_k));
+        TRY_FIN(hipStreamWaitEvent(pipe.s_out, pipe.k_done[k], 0));
+        TRY_FIN(hipMemcpyAsync(h + off * 160, d, n * 160, hipMemcpyDeviceToHost, pipe.s_out));
+        TRY_FIN(hipEventRecord(pipe.out_done[k], pipe.s_out));
+    }
+    TRY_FIN(hipStreamSynchronize(pipe.s_out));           // the last copy-out is behind everything else
+    TRY_FIN(hipStreamSynchronize(pipe.s_k));
+    TRY_FIN(hipStreamSynchronize(pipe.s_in));
 #undef TRY_FIN
     return finish(HADES252_OK);
 }
@@ -1059,18 +1182,25 @@ int hades252_perm_batch_bytes(uint8_t *states, size_t n_perms) {
     return perm_batch_host_on_current_device((uint64_t *)states, n_perms, true);
 }
 
-int hades252_perm_batch_multi(uint64_t *states, size_t n_perms, int n_devices) {
+// Host batch sharded over `n_workers` host threads, worker g taking the contiguous range
+// [n g / W, n (g+1) / W) on device g -- or, with HADES252_MULTI_VIRTUAL, on device g % (visible devices), which lets a
+// box with fewer GPUs than workers run the very code an 8-GPU node runs (several workers then share a device, each
+// with its own pipe).
+int hades252_perm_batch_multi_ex(uint64_t *states, size_t n_perms, int n_workers, unsigned flags) {
+    if (flags & ~(unsigned)HADES252_MULTI_VIRTUAL) return HADES252_ERR_INVALID_ARG;
     if (n_perms == 0) return HADES252_OK;
     if (states == nullptr) return HADES252_ERR_INVALID_ARG;
-    int avail = hades252_device_count();
+    const int avail = hades252_device_count();
     if (avail <= 0) return HADES252_ERR_NO_DEVICE;
-    if (n_devices <= 0) n_devices = avail;
-    if (n_devices > avail) return HADES252_ERR_INVALID_ARG;
-    if ((size_t)n_devices > n_perms) n_devices = (int)n_perms;
+    const bool virt = (flags & HADES252_MULTI_VIRTUAL) != 0;
+    if (n_workers <= 0) n_workers = avail;
+    if (n_workers > (virt ? 64 : avail)) return HADES252_ERR_INVALID_ARG;
+    if ((size_t)n_workers > n_perms) n_workers = (int)n_perms;
     // Page-lock the caller's buffer ONCE for all devices (shards share boundary pages: per-shard registration
     // would overlap and be refused for some shards, by a race); portable = visible to every device.
     bool registered = false;
-    {
+    bool pinned = host_range_pinned(states, n_perms * 160);
+    if (!pinned) {
         const char *e = getenv("HADES252_HOST_PIN");
         if (!(e && e[0] == '0') && n_perms * 160 >= ((size_t)8 << 20)) {
             if (hipHostRegister(states, n_perms * 160, hipHostRegisterPortable) == hipSuccess)
@@ -1079,32 +1209,36 @@ int hades252_perm_batch_multi(uint64_t *states, size_t n_perms, int n_devices) {
                 (void)hipGetLastError();
         }
     }
-    std::vector<int> rcs(n_devices, HADES252_OK);
-    std::vector<int> hip_errs(n_devices, 0);
+    std::vector<int> rcs(n_workers, HADES252_OK);
+    std::vector<int> hip_errs(n_workers, 0);
     std::vector<std::thread> threads;
-    for (int g = 0; g < n_devices; g++) {
+    for (int g = 0; g < n_workers; g++) {
         threads.emplace_back([&, g]() {
-            size_t b = n_perms * (size_t)g / n_devices, e = n_perms * (size_t)(g + 1) / n_devices;
-            hipError_t err = hipSetDevice(g);
+            size_t b = n_perms * (size_t)g / n_workers, e = n_perms * (size_t)(g + 1) / n_workers;
+            hipError_t err = hipSetDevice(virt ? g % avail : g);
             if (err != hipSuccess) {
                 rcs[g] = HADES252_ERR_HIP;
                 hip_errs[g] = (int)err;
                 return;
             }
-            // registered: skip the per-shard attempt; not registered (refused / disabled): also skip it -- a
-            // sub-range attempt would only repeat the refusal -- and use the pageable path
+            // registered or pinned by the caller: skip the per-shard attempt; neither (refused / disabled): also skip
+            // it -- a sub-range attempt would only repeat the refusal -- and use the pageable path
             rcs[g] = perm_batch_host_on_current_device(states + 20 * b, e - b, false, true);
             hip_errs[g] = tl_last_hip_error;
         });
     }
     for (auto &t : threads) t.join();
     if (registered) (void)hipHostUnregister(states);
-    for (int g = 0; g < n_devices; g++)
+    for (int g = 0; g < n_workers; g++)
         if (rcs[g] != HADES252_OK) {
             tl_last_hip_error = hip_errs[g];
             return rcs[g];
         }
     return HADES252_OK;
+}
+
+int hades252_perm_batch_multi(uint64_t *states, size_t n_perms, int n_devices) {
+    return hades252_perm_batch_multi_ex(states, n_perms, n_devices, 0);
 }
 
 int hades252_perm_trace_dev_ex(const void *d_states, void *d_trace, size_t n_perms, void *stream, int kernel) {
@@ -1350,7 +1484,9 @@ static int merkle_run(const uint8_t *leaves, size_t n_leaves, int arity, uint8_t
                 last_n /= arity;
             }
             uint8_t *out_all = tree != nullptr ? tree + off : nullptr;
-            uint8_t *out_last = last_n == 1 ? root : (tree != nullptr ? nullptr : dst_pp);
+            // with a tree every level (the root included: it is the tree's last digest) goes through out_all; the two
+            // pointers are __restrict__ in the kernel and must never name the same bytes
+            uint8_t *out_last = tree != nullptr ? nullptr : (last_n == 1 ? root : dst_pp);
             launch_merkle_coop(arity, src, out_all, out_last, parents, tag, out_idx, n_levels, s);
             HIP_TRY(hipGetLastError());
             src = tree != nullptr ? tree + off + span : dst_pp;

@@ -206,6 +206,57 @@ class ScalarStrategy(Strategy):
             self.apply_full_round(constants, data)
 
 
+class HostBuffer:
+    """Page-locked host memory for the host-pointer path (``hades252_host_alloc`` / ``_free``): what a Rust caller
+    keeps its long-lived ``Vec<BlsScalar>`` in, so that ``perm`` goes straight to DMA instead of page-locking the
+    slice on every call.  ``.array`` is a numpy uint64 view (20 limbs per state); close() frees the memory (the
+    view must not be used afterwards)."""
+
+    def __init__(self, n_states: int):
+        self.ptr = ctypes.c_void_p()
+        self.nbytes = max(1, n_states) * STATE_BYTES
+        check(_lib.lib().hades252_host_alloc(ctypes.byref(self.ptr), self.nbytes), "host_alloc")
+        raw = (ctypes.c_uint64 * (n_states * WIDTH * 4)).from_address(self.ptr.value)
+        self.array = np.frombuffer(raw, dtype=np.uint64)
+
+    def close(self) -> None:
+        if self.ptr:
+            self.array = None
+            check(_lib.lib().hades252_host_free(self.ptr), "host_free")
+            self.ptr = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def host_register(arr: np.ndarray) -> None:
+    """Page-lock an existing host array in place, once (``hades252_host_register``)."""
+    check(_lib.lib().hades252_host_register(arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes), "host_register")
+
+
+def host_unregister(arr: np.ndarray) -> None:
+    check(_lib.lib().hades252_host_unregister(arr.ctypes.data_as(ctypes.c_void_p)), "host_unregister")
+
+
+def host_is_pinned(arr: np.ndarray) -> bool:
+    return bool(_lib.lib().hades252_host_is_pinned(arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes))
+
+
+def perm_multi(data: np.ndarray, n_workers: int = 0, virtual: bool = False) -> None:
+    """``hades252_perm_batch_multi_ex``: a host batch sharded over n_workers host threads / devices (0 = every
+    visible device), contiguous range per worker, no collective.  ``virtual``: worker g runs on device
+    g % device_count, so n_workers may exceed the number of GPUs."""
+    if data.dtype != np.uint64 or not data.flags["C_CONTIGUOUS"]:
+        raise TypeError("perm_multi: host buffers must be C-contiguous numpy uint64")
+    if data.size % (WIDTH * 4) != 0:
+        raise ValueError("perm_multi: %d limbs is not a whole number of %d-word states" % (data.size, WIDTH))
+    check(_lib.lib().hades252_perm_batch_multi_ex(data.ctypes.data_as(ctypes.c_void_p), data.size // (WIDTH * 4),
+                                                  n_workers, _lib.MULTI_VIRTUAL if virtual else 0), "perm_multi")
+
+
 def perm_trace(states_t, kernel: int = _lib.KERNEL_DEFAULT, out=None):
     """State after every round (round-major: result[r] is the batch after round r); the input is
     left untouched.  Witness pre-computation for the reference's GadgetStrategy

@@ -27,8 +27,9 @@
  *     pointers need only their natural 8-byte alignment.
  *   - Thread-safe and re-entrant: any number of host threads may call concurrently (the reference's
  *     strategy is a stateless ZST, src/strategies/scalar.rs:11-20).  The only internal state is a
- *     mutex-protected pool of scratch slots (stream + device buffer) used by the host-pointer
- *     entry points; device tables are immutable.
+ *     mutex-protected pool of pipes (three streams + chunk buffers in device memory) used by the
+ *     host-pointer entry points and the list of host ranges pinned through this library; device
+ *     tables are immutable.
  *   - There is no CPU fallback: without a usable HIP device the calls fail with
  *     HADES252_ERR_NO_DEVICE / HADES252_ERR_HIP.
  */
@@ -81,8 +82,29 @@ int hades252_perm_batch_bytes(uint8_t *states, size_t n_perms);
 int hades252_perm_batch_dev(void *d_states, size_t n_perms, void *stream);
 int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int kernel);
 /* Host batch sharded over the first n_devices GPUs (contiguous ranges, one host thread and
- * stream per device, no collective).  n_devices <= 0 means all visible devices. */
+ * pipe per device, no collective).  n_devices <= 0 means all visible devices. */
 int hades252_perm_batch_multi(uint64_t *states, size_t n_perms, int n_devices);
+/* Same with n_workers host threads; flags = HADES252_MULTI_VIRTUAL maps worker g to device g % (visible devices)
+ * instead of device g, so that n_workers may exceed the device count (up to 64): a one-GPU box then runs the code
+ * path of an 8-GPU node, several workers sharing a device.  Worker g owns states [n g / W, n (g+1) / W). */
+#define HADES252_MULTI_VIRTUAL 1u
+int hades252_perm_batch_multi_ex(uint64_t *states, size_t n_perms, int n_workers, unsigned flags);
+
+/* ---- page-locked host memory for the host-pointer entry points ---------------------------------------
+ * The reference's caller holds its states in ordinary memory (`&mut [BlsScalar]`, src/strategies.rs:140).  DMA needs
+ * page-locked memory, and locking / unlocking a buffer on every call costs more than moving it.  A caller with a
+ * long-lived buffer pins it ONCE: either allocate it here, or register an existing allocation; hades252_perm_batch*
+ * recognise such memory (and memory the caller pinned through HIP itself) and go straight to DMA.  Anything else is
+ * page-locked per call when >= 8 MiB (environment HADES252_HOST_PIN=0 disables that), else copied as pageable memory.
+ *   hades252_host_alloc      bytes of page-locked host memory, usable from every device; free with hades252_host_free
+ *   hades252_host_register   page-lock [p, p + bytes) in place (any alignment); undo with hades252_host_unregister(p)
+ *   hades252_host_is_pinned  1 if [p, p + bytes) is page-locked (by either call or through HIP), else 0
+ * free / unregister return HADES252_ERR_INVALID_ARG for a pointer that did not come from alloc / register. */
+int hades252_host_alloc(void **out, size_t bytes);
+int hades252_host_free(void *p);
+int hades252_host_register(void *p, size_t bytes);
+int hades252_host_unregister(void *p);
+int hades252_host_is_pinned(const void *p, size_t bytes);
 
 /* Per-round trace (witness pre-computation for GadgetStrategy, src/strategies/gadget.rs:41-133):
  * d_trace receives 67 batches, round-major: trace[r] (n_perms x 160 B, same AoS format) is the

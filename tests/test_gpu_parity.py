@@ -250,7 +250,7 @@ def test_host_entry_points(torch_cuda, hades_lib, H, oracle):
 
 
 def test_host_path_chunked(torch_cuda, hades_lib, H, oracle):
-    """More than one 2^18 chunk: exercises the double-buffered H2D / kernel / D2H pipeline."""
+    """Several chunks: exercises the event-chained copy-in / kernel / copy-out pipeline (pageable caller memory)."""
     n = (1 << 18) * 2 + 12345
     buf = H.gen_b(5 * n, "cuda")
     inp = to_host(buf).copy()
