@@ -153,12 +153,15 @@ def launch_ranks(args) -> int:
     rc = 0
     try:
         live = list(procs)
-        while live and rc == 0:
+        deadline = None                   # set by the first failure: the others get a few seconds to fail by themselves
+        while live and (deadline is None or time.time() < deadline):
             time.sleep(0.05)
             for p in list(live):
                 if p.poll() is not None:
                     live.remove(p)
                     rc = rc or p.returncode
+            if rc != 0 and deadline is None:
+                deadline = time.time() + 5.0
     finally:
         for p in procs:
             if p.poll() is None:
@@ -369,7 +372,9 @@ def main():
                     "SIMDs x 2.4 GHz / 4 cycles (ideal pipe at the peak clock); only fewer instructions can make the "
                     "kernel faster (DESIGN.md section 5)"}
     if not args.no_cpu_baseline:
-        cb, ok = cpu_baseline_and_check(H, torch, device, args.cpu_sample, args.kernel or _lib.KERNEL_FAST)
+        # checked with the kernel that was timed, whatever the sample size would make the default dispatch pick
+        timed_kernel = args.kernel or (_lib.KERNEL_COOP if n <= COOP_MAX_STATES else _lib.KERNEL_FAST)
+        cb, ok = cpu_baseline_and_check(H, torch, device, args.cpu_sample, timed_kernel)
         out["cpu_baseline"] = cb
         out["parity_vs_cpu_sample"] = all_ok = all_ok and ok
     if not args.no_secondary:

@@ -28,8 +28,13 @@ def test_bench_single_and_two_ranks_agree():
     per = 1 << 18
     one = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--perms-per-gpu", str(2 * per),
                "--cpu-sample", "4096"])
-    for k in REQUIRED + ["cpu_baseline"]:
+    for k in REQUIRED + ["cpu_baseline", "secondary"]:
         assert k in one, k
+    # outside `value`: BASELINE configs[3] and the host-pointer boundary (native caller, PCIe-inclusive)
+    mk, hp = one["secondary"]["merkle_2p24"], one["secondary"]["host_path"]
+    assert mk["nodes"] == 5592405 and 0 < mk["tree_ms"] < 100 and mk["roofline"]["algorithmic_bytes_per_node"] == 160
+    assert hp["bit_exact_vs_device_path"] is True and 0 < hp["frac_of_ceiling"] < 1.2 and hp["perms"] == 1 << 22
+    assert one["config"]["kernel"] == "k_perm_fast" and "valu_issue" in one and "frac_of_measured" not in one["valu_issue"]
     assert one["n_gpus"] == 1 and one["parity_vs_cpu_sample"] is True
     assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1
     assert one["cpu_baseline"]["kind"] == "port" and one["cpu_baseline"]["cores"] >= 1
@@ -37,15 +42,16 @@ def test_bench_single_and_two_ranks_agree():
     two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200),
                "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--perms-per-gpu", str(per),
-               "--dist-backend", "gloo", "--single-device"])
-    assert two["n_gpus"] == 2 and "cpu_baseline" not in two
+               "--dist-backend", "gloo", "--single-device", "--cpu-sample", "4096", "--no-secondary"])
+    assert two["n_gpus"] == 2 and two["cpu_baseline"]["kind"] == "port" and "secondary" not in two
     # same global batch (2 x per states, same generator indices), same number of passes
     assert two["digest"] == one["digest"]
     assert two["parity_vs_cpu_sample"] is True and len(two["per_gpu"]["kernel_ms_per_rank"]) == 2
     # self-launch: `python bench.py --gpus 2` with no torchrun around it spawns its own ranks
     env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--perms-per-gpu",
-                        str(per), "--dist-backend", "gloo", "--single-device"], cwd=ROOT, capture_output=True, text=True,
+                        str(per), "--dist-backend", "gloo", "--single-device", "--cpu-sample", "4096", "--no-secondary"],
+                       cwd=ROOT, capture_output=True, text=True,
                        timeout=900, env=env_clean)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -53,3 +59,14 @@ def test_bench_single_and_two_ranks_agree():
     self_launched = json.loads(lines[0])
     assert self_launched["n_gpus"] == 2 and self_launched["digest"] == one["digest"]
     assert self_launched["parity_vs_cpu_sample"] is True
+
+
+def test_bench_reports_the_kernel_that_ran():
+    """--perms-per-gpu <= 16384 with the default dispatch runs the five-waves kernel: the line must say so and must not
+    attribute k_perm_fast's instruction counts / traffic profile to it."""
+    small = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--perms-per-gpu", "8192", "--cpu-sample",
+                 "4096", "--no-secondary"])
+    assert small["config"]["kernel"] == "k_perm_coop" and small["roofline"]["kernel"] == "k_perm_coop"
+    assert "valu_issue" not in small and small["roofline"]["traffic"] is None and small["parity_vs_cpu_sample"] is True
+    mk = run([sys.executable, "bench.py", "--workload", "merkle", "--steps", "3"])
+    assert mk["unit"] == "nodes/s" and mk["roofline"]["algorithmic_bytes_per_node"] == 160 and mk["value"] > 1e8
