@@ -22,6 +22,7 @@ KERNEL_DEFAULT = 0
 KERNEL_LITERAL = 1
 KERNEL_FAST = 2
 KERNEL_COOP = 3
+KERNEL_LANES = 4
 MULTI_VIRTUAL = 1
 
 # every symbol include/hades252.h declares: name -> (restype, argtypes)
@@ -58,6 +59,22 @@ SIGNATURES = {
     "hades252_from_bytes_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "hades252_to_bytes_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "hades252_merkle_level_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_int, POINTER(c_uint64), c_int, c_void_p]),
+    "hades252_merkle_depth": (c_int, [c_size_t, c_int]),
+    "hades252_merkle_level_pad_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_int, POINTER(c_uint64), c_int, c_void_p,
+                                              c_void_p]),
+    "hades252_merkle_root_pad_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_size_t, POINTER(c_uint64), c_int,
+                                             c_void_p, c_void_p, c_void_p]),
+    "hades252_merkle_build_pad_dev": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_uint64), c_int, c_void_p, c_void_p,
+                                              c_void_p]),
+    "hades252_merkle_empty_digests_dev": (c_int, [c_int, c_int, POINTER(c_uint64), POINTER(c_uint64), c_int, c_void_p,
+                                                  c_void_p]),
+    "hades252_merkle_open_pad_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p,
+                                             c_void_p]),
+    "hades252_merkle_verify_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, POINTER(c_uint64), c_int,
+                                           c_void_p, c_void_p]),
+    "hades252_merkle_forest_scratch_bytes": (c_size_t, [c_size_t, c_size_t, c_int]),
+    "hades252_merkle_forest_dev": (c_int, [c_void_p, c_size_t, c_size_t, c_int, c_void_p, c_size_t, POINTER(c_uint64),
+                                           c_int, c_void_p, c_void_p]),
     "hades252_merkle_scratch_bytes": (c_size_t, [c_size_t, c_int]),
     "hades252_merkle_root_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_size_t, POINTER(c_uint64), c_int,
                                          c_void_p, c_void_p]),

@@ -22,7 +22,7 @@ LIB = os.path.join(CSRC, "libhades252.so")
 STAMP = LIB + ".stamp"
 LOCK = LIB + ".lock"
 SOURCES = ["hades252.hip"]
-DEPS = ["hades252.hip", "fr32.cuh", "staging.cuh", "hades_literal.cuh", "hades_fast.cuh", "k_perm_fast.cuh", "hades_coop.cuh",
+DEPS = ["hades252.hip", "fr32.cuh", "staging.cuh", "hades_literal.cuh", "hades_fast.cuh", "k_perm_fast.cuh", "hades_coop.cuh", "hades_lanes.cuh",
         "hades_constants.inc", os.path.join("..", "..", "include", "hades252.h")]
 # what the dominant kernel (k_perm_fast) is made of: profiles recorded for it stay valid while these are unchanged
 PERM_FAST_DEPS = ["fr32.cuh", "staging.cuh", "hades_fast.cuh", "k_perm_fast.cuh"]

@@ -17,6 +17,7 @@
 #include "hades_fast.cuh"
 #include "k_perm_fast.cuh"
 #include "hades_coop.cuh"
+#include "hades_lanes.cuh"
 
 using namespace hades;
 
@@ -34,6 +35,9 @@ __device__ const uint32_t d_r2[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b
 // d_fast (the throughput kernel's round records) is defined next to its kernel in k_perm_fast.cuh
 // low-latency schedule (hades_coop.cuh)
 __device__ const CoopTables d_coop = {HADES_COOP_ROUND_INIT, HADES_COOP_FINAL_F, HADES_FAST_MDS_SMALL};
+// lane-split schedule (hades_lanes.cuh): the coop schedule with plain-limb round constants + the reduction constants
+__device__ const LanesTables d_lanes = {HADES_LANES_ROUND_INIT, HADES_COOP_FINAL_F, HADES_FAST_MDS_SMALL, HADES_P29,
+                                        HADES_P29, HADES_NEG_PINV29};
 // trace kernel: U_r with mont(X_after_round_r, U_r) = x * 2^256
 __device__ const int32_t d_trace_u[67][16] = HADES_FAST_TRACE_U_INIT;
 // ... + D_r: the partial-round constants of words 0..3 that the shipped schedule defers (hades_fast.cuh item 5)
@@ -58,6 +62,26 @@ __device__ const int32_t d_rp2_over_r[16] = HADES_RP2_OVER_R29;
 // ------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ Fr load_word(const uint8_t *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    const uint4 lo = q[0], hi = q[1];
+    Fr w;
+    w.l[0] = lo.x; w.l[1] = lo.y; w.l[2] = lo.z; w.l[3] = lo.w;
+    w.l[4] = hi.x; w.l[5] = hi.y; w.l[6] = hi.z; w.l[7] = hi.w;
+    return w;
+}
+__device__ __forceinline__ void store_word(uint8_t *p, const Fr &w) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]);
+    q[1] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]);
+}
+__device__ __forceinline__ Fr zero_word() {
+    Fr w;
+#pragma unroll
+    for (int i = 0; i < 8; i++) w.l[i] = 0;
+    return w;
+}
+
 enum Op { OP_PERM = 0, OP_ARK, OP_MDS, OP_FULL, OP_PARTIAL };
 
 // st[4] <- st[3] <- ... <- st[0] <- st[4]: loops over the five words rotate the state through ONE code body
@@ -364,31 +388,70 @@ __global__ void __launch_bounds__(kBlock) k_wire(const uint8_t *in, uint8_t *out
     }
 }
 
-// One Merkle level, one parent per lane: parent = perm([tag, c_0 .. c_{ARITY-1}, 0 ..])[out_idx]
-// (arity 4 fills the state: the caller shape of dusk-poseidon, README.md:9; arity 2 leaves two zero words).
+// One Merkle level, one parent per lane: parent = perm([tag, c_0 .. c_{ARITY-1}, 0 ..])[out_idx], ARITY = 1 .. 4
+// (arity 4 fills the state: the caller shape of dusk-poseidon, README.md:9; smaller arities leave zero words).
+// The level may be ragged: n_children need not be a multiple of ARITY; a child position past the end of the level takes
+// the digest at `pad` (device memory, 32 B; NULL = the zero scalar) -- the "empty subtree" digest of that level.
+__device__ __forceinline__ Fr load_pad(const uint8_t *pad) { return pad != nullptr ? load_word(pad) : zero_word(); }
+
 template <int ARITY>
-__global__ void __launch_bounds__(kBlock, 4) k_merkle_level_fast(const uint8_t *__restrict__ children,
+__global__ void __launch_bounds__(kBlock, 4) k_merkle_level_fast(const uint8_t *__restrict__ children, size_t n_children,
                                                                  uint8_t *__restrict__ parents, size_t n_parents,
-                                                                 Fr tag, int out_idx) {
+                                                                 Fr tag, int out_idx, const uint8_t *__restrict__ pad) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *slab = wave_slab<ARITY>(lds);
     size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
     Fr ch[ARITY];
-    wave_load_records<ARITY>(children, rec0, n_parents, slab, ch);
+    wave_load_scalars<ARITY>(children, rec0, n_children, slab, ch);
+    const size_t first = (rec0 + (threadIdx.x & (kWave - 1))) * ARITY;
+    if (first + ARITY > n_children) {                      // at most one lane of the grid with live data gets here
+        const Fr pd = load_pad(pad);
+#pragma unroll
+        for (int w = 0; w < ARITY; w++)
+            if (first + w >= n_children) ch[w] = pd;
+    }
     Fr st[5];
     st[0] = tag;
 #pragma unroll
-    for (int w = 1; w < 5; w++) {
-        if (w <= ARITY) {
-            st[w] = ch[w <= ARITY ? w - 1 : 0];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; i++) st[w].l[i] = 0;
-        }
-    }
+    for (int w = 1; w < 5; w++) st[w] = w <= ARITY ? ch[w <= ARITY ? w - 1 : 0] : zero_word();
     Fr out[1];
     fast_perm<1>(&d_fast, st, out, out_idx);
     wave_store_records<1>(parents, rec0, n_parents, slab, out);
+}
+
+// Path verification: lane q recomputes the root from leaf q and its opening (the siblings of hades252_merkle_open_dev:
+// level l, child order, own position (index / ARITY^l) % ARITY skipped) -- `depth` dependent permutations per lane.
+template <int ARITY>
+__global__ void __launch_bounds__(kBlock, 3) k_merkle_verify(const uint8_t *__restrict__ leaves,
+                                                             const uint64_t *__restrict__ indices,
+                                                             const uint8_t *__restrict__ paths, size_t n_queries, int depth,
+                                                             Fr tag, int out_idx, uint8_t *__restrict__ roots) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<1>(lds);
+    const size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    const size_t q = rec0 + (threadIdx.x & (kWave - 1));
+    const bool live = q < n_queries;
+    Fr node[1];
+    wave_load_records<1>(leaves, rec0, n_queries, slab, node);
+    uint64_t idx = live ? indices[q] : 0;
+    const uint8_t *mine = paths + q * (size_t)depth * (ARITY - 1) * 32;
+#pragma unroll 1
+    for (int l = 0; l < depth; l++) {
+        const int pos = (int)(idx % ARITY);
+        idx /= ARITY;
+        Fr st[5];
+        st[0] = tag;
+#pragma unroll
+        for (int w = 1; w < 5; w++) st[w] = zero_word();
+#pragma unroll
+        for (int c = 0; c < ARITY; c++) {                 // child c: the node itself at `pos`, else the next sibling
+            Fr v = node[0];
+            if (c != pos && live) v = load_word(mine + ((size_t)l * (ARITY - 1) + (c < pos ? c : c - 1)) * 32);
+            st[1 + c] = v;
+        }
+        fast_perm<1>(&d_fast, st, node, out_idx);
+    }
+    wave_store_records<1>(roots, rec0, n_queries, slab, node);
 }
 
 // ---- low-latency kernels: five waves per state (hades_coop.cuh) --------------------------------------
@@ -430,6 +493,40 @@ __global__ void __launch_bounds__(kCoopThreads) k_perm_coop(uint8_t *states, siz
         uint4 v = *reinterpret_cast<const uint4 *>(L.stage + rec * 176 + part * 16);
         if (chunk0 + c < total) g[c] = v;
     }
+}
+
+// ---- lowest-latency kernels: one state per WAVE, every field element spread over a 16-lane row (hades_lanes.cuh) ---
+constexpr int kLanesWaves = 4;                   // states per block
+// In-place permutation, one state per wave (no block-wide barrier anywhere: idle waves simply leave).
+__global__ void __launch_bounds__(kLanesWaves *kWave) k_perm_lanes(uint8_t *states, size_t n) {
+    __shared__ LanesLds L[kLanesWaves];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    const size_t rec = (size_t)blockIdx.x * kLanesWaves + wave;
+    if (rec >= n) return;
+    uint8_t *mine = states + rec * 160 + (lane < 5 ? lane : 0) * 32;
+    const Fr in = lane < 5 ? load_word(mine) : zero_word();
+    const Fr out = lanes_perm(&d_lanes, L[wave], in);
+    if (lane < 5) store_word(mine, out);
+}
+
+// One Merkle level, one parent per wave: parent = perm([tag, c_0 .. c_{ARITY-1}, 0 ..])[out_idx]; ragged levels and
+// `pad` as in k_merkle_level_fast.
+template <int ARITY>
+__global__ void __launch_bounds__(kLanesWaves *kWave) k_merkle_lanes(const uint8_t *__restrict__ children, size_t n_children,
+                                                                     uint8_t *__restrict__ parents, size_t n_parents,
+                                                                     Fr tag, int out_idx, const uint8_t *__restrict__ pad) {
+    __shared__ LanesLds L[kLanesWaves];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    const size_t rec = (size_t)blockIdx.x * kLanesWaves + wave;
+    if (rec >= n_parents) return;
+    Fr in = zero_word();
+    if (lane == 0) in = tag;
+    if (lane >= 1 && lane <= ARITY) {
+        const size_t c = rec * ARITY + (lane - 1);
+        in = c < n_children ? load_word(children + c * 32) : load_pad(pad);
+    }
+    const Fr out = lanes_perm(&d_lanes, L[wave], in);
+    if (lane == out_idx) store_word(parents + rec * 32, out);
 }
 
 // Fused Merkle levels: block b takes the children of parents [64b, 64b + 64) of one level (n_parents in
@@ -508,12 +605,13 @@ __global__ void __launch_bounds__(kCoopThreads) k_merkle_coop(const uint8_t *__r
 // Openings (authentication paths): for query t with leaf index idx, level l = 0 .. depth-1, the ARITY-1
 // siblings of the path node at that level, in child order with the path node's own position skipped:
 //   paths[t][l][s] (32 B each).  Level 0 siblings are leaves, level l >= 1 siblings are digests of tree level
-//   l-1 (layout of hades252_merkle_build_dev).  One thread per 16-byte half digest.
+//   l-1 (layout of hades252_merkle_build_dev; level sizes n_l = ceil(n_{l-1} / ARITY)).  A sibling position past the
+//   end of its level is the level's padding digest pad[l] (NULL = zero).  One thread per 16-byte half digest.
 template <int ARITY>
 __global__ void __launch_bounds__(kBlock) k_merkle_open(const uint8_t *__restrict__ leaves,
                                                         const uint8_t *__restrict__ tree, size_t n_leaves, int depth,
                                                         const uint64_t *__restrict__ indices, size_t n_queries,
-                                                        uint8_t *__restrict__ paths) {
+                                                        uint8_t *__restrict__ paths, const uint8_t *__restrict__ pad) {
     const size_t per_query = (size_t)depth * (ARITY - 1) * 2;
     const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (tid >= n_queries * per_query) return;
@@ -529,14 +627,18 @@ __global__ void __launch_bounds__(kBlock) k_merkle_open(const uint8_t *__restric
     size_t level_n = n_leaves, off = 0;
     for (int i = 0; i < l; i++) {
         node /= ARITY;
-        level_n /= ARITY;
+        level_n = (level_n + ARITY - 1) / ARITY;
         level = tree + off;
         off += level_n * 32;
     }
     const size_t first = node - node % ARITY;
     const int pos = (int)(node % ARITY);
     const int sib = s < pos ? s : s + 1;
-    const uint4 v = *reinterpret_cast<const uint4 *>(level + (first + sib) * 32 + half * 16);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (first + sib < level_n)
+        v = *reinterpret_cast<const uint4 *>(level + (first + sib) * 32 + half * 16);
+    else if (pad != nullptr)
+        v = *reinterpret_cast<const uint4 *>(pad + (size_t)l * 32 + half * 16);
     *reinterpret_cast<uint4 *>(paths + tid * 16) = v;
 }
 
@@ -740,26 +842,66 @@ static Fr fr_from_u64(const uint64_t v[4]) {
 // a batch this small is latency-bound: the five-waves-per-state kernel finishes it in less than half the time
 // of one per-lane wave (crossover measured on MI355X: profiles/r2/time_paths.txt)
 static constexpr size_t kCoopMaxStates = (size_t)1 << 14;
+// ... and one this small (at most one wave per SIMD) is fastest with one state per wave, every product spread over a
+// 16-lane row (hades_lanes.cuh): about half the latency of the five-waves kernel
+static constexpr size_t kLanesMaxStates = (size_t)1 << 10;
 
-static void launch_merkle_level(int arity, const uint8_t *children, uint8_t *parents, size_t n, Fr tag, int out_idx,
-                                hipStream_t s) {
-    if (arity == 4)
-        hipLaunchKernelGGL(k_merkle_level_fast<4>, dim3(blocks_for(n)), dim3(kBlock), lds_for(4), s, children, parents,
-                           n, tag, out_idx);
-    else
-        hipLaunchKernelGGL(k_merkle_level_fast<2>, dim3(blocks_for(n)), dim3(kBlock), lds_for(2), s, children, parents,
-                           n, tag, out_idx);
+// one parent per lane (any size, any arity, ragged levels)
+static void launch_merkle_level(int arity, const uint8_t *children, size_t n_children, uint8_t *parents, size_t n, Fr tag,
+                                int out_idx, const uint8_t *pad, hipStream_t s) {
+#define HADES_LAUNCH_LEVEL(A)                                                                                         \
+    hipLaunchKernelGGL(k_merkle_level_fast<A>, dim3(blocks_for(n)), dim3(kBlock), lds_for(A), s, children, n_children, \
+                       parents, n, tag, out_idx, pad)
+    switch (arity) {
+        case 1: HADES_LAUNCH_LEVEL(1); break;
+        case 2: HADES_LAUNCH_LEVEL(2); break;
+        case 3: HADES_LAUNCH_LEVEL(3); break;
+        default: HADES_LAUNCH_LEVEL(4); break;
+    }
+#undef HADES_LAUNCH_LEVEL
 }
 
+// one parent per wave (small levels: lowest latency)
+static void launch_merkle_lanes(int arity, const uint8_t *children, size_t n_children, uint8_t *parents, size_t n, Fr tag,
+                                int out_idx, const uint8_t *pad, hipStream_t s) {
+    const dim3 grid((unsigned)((n + kLanesWaves - 1) / kLanesWaves)), block(kLanesWaves * kWave);
+#define HADES_LAUNCH_LANES(A) \
+    hipLaunchKernelGGL(k_merkle_lanes<A>, grid, block, 0, s, children, n_children, parents, n, tag, out_idx, pad)
+    switch (arity) {
+        case 1: HADES_LAUNCH_LANES(1); break;
+        case 2: HADES_LAUNCH_LANES(2); break;
+        case 3: HADES_LAUNCH_LANES(3); break;
+        default: HADES_LAUNCH_LANES(4); break;
+    }
+#undef HADES_LAUNCH_LANES
+}
+
+// five waves per parent, full levels only (n_children = arity * n_parents); n_levels > 1 only for arity 2 and 4
 static void launch_merkle_coop(int arity, const uint8_t *children, uint8_t *out_all, uint8_t *out_last, size_t n_parents,
                                Fr tag, int out_idx, int n_levels, hipStream_t s) {
     const unsigned grid = (unsigned)((n_parents + kCoopStates - 1) / kCoopStates);
-    if (arity == 4)
-        hipLaunchKernelGGL(k_merkle_coop<4>, dim3(grid), dim3(kCoopThreads), 0, s, children, out_all, out_last,
-                           n_parents, tag, out_idx, n_levels);
+#define HADES_LAUNCH_COOP(A)                                                                                  \
+    hipLaunchKernelGGL(k_merkle_coop<A>, dim3(grid), dim3(kCoopThreads), 0, s, children, out_all, out_last, \
+                       n_parents, tag, out_idx, n_levels)
+    switch (arity) {
+        case 1: HADES_LAUNCH_COOP(1); break;
+        case 2: HADES_LAUNCH_COOP(2); break;
+        case 3: HADES_LAUNCH_COOP(3); break;
+        default: HADES_LAUNCH_COOP(4); break;
+    }
+#undef HADES_LAUNCH_COOP
+}
+
+// One level, the kernel chosen by size: `n_children` children -> ceil(n_children / arity) parents.
+static void launch_merkle_any(int arity, const uint8_t *children, size_t n_children, uint8_t *parents, Fr tag, int out_idx,
+                              const uint8_t *pad, hipStream_t s) {
+    const size_t n_parents = (n_children + arity - 1) / arity;
+    if (n_parents <= kLanesMaxStates)
+        launch_merkle_lanes(arity, children, n_children, parents, n_parents, tag, out_idx, pad, s);
+    else if (n_parents <= kCoopMaxStates && n_children % arity == 0)
+        launch_merkle_coop(arity, children, nullptr, parents, n_parents, tag, out_idx, 1, s);
     else
-        hipLaunchKernelGGL(k_merkle_coop<2>, dim3(grid), dim3(kCoopThreads), 0, s, children, out_all, out_last,
-                           n_parents, tag, out_idx, n_levels);
+        launch_merkle_level(arity, children, n_children, parents, n_parents, tag, out_idx, pad, s);
 }
 
 static int check_device() {
@@ -810,10 +952,15 @@ int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int
     hipStream_t s = (hipStream_t)stream;
     uint8_t *p = (uint8_t *)d_states;
     // small batches are latency-bound: five waves per state (hades_coop.cuh); large ones one state per lane
-    if (kernel == HADES252_KERNEL_DEFAULT) kernel = n_perms <= kCoopMaxStates ? HADES252_KERNEL_COOP : HADES252_KERNEL_FAST;
+    if (kernel == HADES252_KERNEL_DEFAULT)
+        kernel = n_perms <= kLanesMaxStates ? HADES252_KERNEL_LANES
+                                            : (n_perms <= kCoopMaxStates ? HADES252_KERNEL_COOP : HADES252_KERNEL_FAST);
     for (size_t off = 0; off < n_perms; off += kMaxLaunchRecords) {
         size_t n = n_perms - off < kMaxLaunchRecords ? n_perms - off : kMaxLaunchRecords;
-        if (kernel == HADES252_KERNEL_COOP) {
+        if (kernel == HADES252_KERNEL_LANES) {
+            hipLaunchKernelGGL(k_perm_lanes, dim3((unsigned)((n + kLanesWaves - 1) / kLanesWaves)),
+                               dim3(kLanesWaves * kWave), 0, s, p + off * 160, n);
+        } else if (kernel == HADES252_KERNEL_COOP) {
             hipLaunchKernelGGL(k_perm_coop, dim3((unsigned)((n + kCoopStates - 1) / kCoopStates)), dim3(kCoopThreads), 0,
                                s, p + off * 160, n);
         } else if (kernel == HADES252_KERNEL_LITERAL) {
@@ -1374,7 +1521,7 @@ int hades252_to_bytes_dev(const void *d_limbs, void *d_bytes, size_t n_scalars, 
 
 // ---- Merkle ----------------------------------------------------------------------------------
 static int log_arity(size_t n, int arity) {          // n = arity^k -> k, else -1
-    if (arity != 2 && arity != 4) return -1;
+    if (arity < 2 || arity > 4) return -1;
     int k = 0;
     while (n > 1) {
         if (n % arity) return -1;
@@ -1384,22 +1531,36 @@ static int log_arity(size_t n, int arity) {          // n = arity^k -> k, else -
     return n == 1 ? k : -1;
 }
 
-int hades252_merkle_level_dev(const void *d_children, void *d_parents, size_t n_parents, int arity,
-                              const uint64_t tag_mont[4], int out_idx, void *stream) {
-    if (arity != 2 && arity != 4) return HADES252_ERR_INVALID_ARG;
-    if (n_parents == 0) return HADES252_OK;
+// levels above the leaves of a tree over n_leaves leaves: n_l = ceil(n_{l-1} / arity) until one node is left
+int hades252_merkle_depth(size_t n_leaves, int arity) {
+    if (arity < 2 || arity > 4 || n_leaves < 2) return -1;
+    int d = 0;
+    while (n_leaves > 1) {
+        n_leaves = (n_leaves + arity - 1) / arity;
+        d++;
+    }
+    return d;
+}
+
+int hades252_merkle_level_pad_dev(const void *d_children, size_t n_children, void *d_parents, int arity,
+                                  const uint64_t tag_mont[4], int out_idx, const void *d_pad, void *stream) {
+    if (arity < 1 || arity > 4) return HADES252_ERR_INVALID_ARG;
+    if (n_children == 0) return HADES252_OK;
+    const size_t n_parents = (n_children + arity - 1) / arity;
     if (d_children == nullptr || d_parents == nullptr || tag_mont == nullptr || out_idx < 0 || out_idx >= 5 ||
-        n_parents > kMaxLaunchRecords || misaligned(d_children) || misaligned(d_parents))
+        n_parents > kMaxLaunchRecords || misaligned(d_children) || misaligned(d_parents) || misaligned(d_pad))
         return HADES252_ERR_INVALID_ARG;
-    const Fr tag = fr_from_u64(tag_mont);
-    if (n_parents <= kCoopMaxStates)
-        launch_merkle_coop(arity, (const uint8_t *)d_children, nullptr, (uint8_t *)d_parents, n_parents, tag, out_idx, 1,
-                           (hipStream_t)stream);
-    else
-        launch_merkle_level(arity, (const uint8_t *)d_children, (uint8_t *)d_parents, n_parents, tag, out_idx,
-                            (hipStream_t)stream);
+    launch_merkle_any(arity, (const uint8_t *)d_children, n_children, (uint8_t *)d_parents, fr_from_u64(tag_mont), out_idx,
+                      (const uint8_t *)d_pad, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return HADES252_OK;
+}
+
+int hades252_merkle_level_dev(const void *d_children, void *d_parents, size_t n_parents, int arity,
+                              const uint64_t tag_mont[4], int out_idx, void *stream) {
+    if (arity < 1 || arity > 4 || n_parents > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    return hades252_merkle_level_pad_dev(d_children, n_parents * (size_t)arity, d_parents, arity, tag_mont, out_idx, nullptr,
+                                         stream);
 }
 
 int hades252_merkle4_level_dev(const void *d_children, void *d_parents, size_t n_parents, const uint64_t tag_mont[4],
@@ -1445,71 +1606,99 @@ int hades252_sponge_hash_var_dev(const void *d_scalars, size_t n_scalars, const 
 }
 
 size_t hades252_merkle_tree_bytes(size_t n_leaves, int arity) {
-    if (log_arity(n_leaves, arity) < 1) return 0;
-    return (n_leaves - 1) / (size_t)(arity - 1) * 32;          // n/A + n/A^2 + ... + 1 digests
+    if (hades252_merkle_depth(n_leaves, arity) < 1) return 0;
+    size_t total = 0;
+    while (n_leaves > 1) {
+        n_leaves = (n_leaves + arity - 1) / arity;
+        total += n_leaves;                                     // n_1 + n_2 + ... + 1 digests
+    }
+    return total * 32;
 }
 
 size_t hades252_merkle_scratch_bytes(size_t n_leaves, int arity) {
-    // two ping-pong buffers: level 1 (n/A digests) and level 2 (n/A^2); a single-level tree needs none
-    if (log_arity(n_leaves, arity) < 2) return 0;
-    return (n_leaves / arity) * 32 + (n_leaves / arity / arity) * 32;
+    // two ping-pong buffers: level 1 (n_1 digests) and level 2 (n_2); a single-level tree needs none
+    if (hades252_merkle_depth(n_leaves, arity) < 2) return 0;
+    const size_t n1 = (n_leaves + arity - 1) / arity, n2 = (n1 + arity - 1) / arity;
+    return (n1 + n2) * 32;
 }
+/* arity-4 form; 0 also for a one-level tree (4 leaves need no scratch) -- hades252_merkle_depth tells valid from invalid */
 size_t hades252_merkle4_scratch_bytes(size_t n_leaves) { return hades252_merkle_scratch_bytes(n_leaves, 4); }
 
-// The whole tree.  Levels with more than kCoopMaxStates parents run one parent per lane (throughput);
-// from there on the five-waves-per-state kernel takes 64 parents per block through up to log_A(64) + 1 levels
-// inside the CU (k_merkle_coop) -- a 65 536-leaf arity-4 tree is two launches.
+// The whole tree over any number of leaves >= 2, arity 2 .. 4.  Levels with more than kCoopMaxStates parents run one
+// parent per lane (throughput); full levels of 1 025 .. 16 384 parents run five waves per parent, with arity 2 / 4 and a
+// power-of-arity level taking 64 parents per block through several levels inside the CU (k_merkle_coop) as long as
+// the next level is still that large; levels of at most kLanesMaxStates parents run one parent per wave
+// (k_merkle_lanes: ~59 us per level instead of ~104).  Ragged levels: a child position past the end of level l takes
+// pad[l] (device table of depth digests, NULL = zeros).
 // tree != NULL: every level is kept (layout of hades252_merkle_build_dev); else ping-pong in buf_a / buf_b.
 static int merkle_run(const uint8_t *leaves, size_t n_leaves, int arity, uint8_t *tree, uint8_t *buf_a, uint8_t *buf_b,
-                      uint8_t *root, const Fr &tag, int out_idx, hipStream_t s) {
-    const int per_block_levels = log_arity(kCoopStates, arity) + 1;       // 64 parents -> 1 digest
+                      uint8_t *root, const Fr &tag, int out_idx, const uint8_t *pad, hipStream_t s) {
     const uint8_t *src = leaves;
     size_t n = n_leaves, off = 0;
     bool to_a = true;
+    int level = 0;
     while (n > 1) {
-        const size_t parents = n / arity;
+        const size_t parents = (n + arity - 1) / arity;
+        const uint8_t *pad_l = pad != nullptr ? pad + (size_t)level * 32 : nullptr;
         uint8_t *dst_pp = to_a ? buf_a : buf_b;
-        if (parents > kCoopMaxStates) {
-            uint8_t *dst = tree != nullptr ? tree + off : dst_pp;
-            launch_merkle_level(arity, src, dst, parents, tag, out_idx, s);
-            HIP_TRY(hipGetLastError());
-            off += parents * 32;
-            src = dst;
-            n = parents;
-        } else {
-            const int n_levels = parents < (size_t)kCoopStates ? log_arity(parents, arity) + 1 : per_block_levels;
+        int fused = 1;
+        if ((arity == 2 || arity == 4) && parents > kLanesMaxStates && parents <= kCoopMaxStates && log_arity(n, arity) > 0) {
+            // fuse while the level after the last fused one is still too large for one-parent-per-wave
+            const int max_fused = log_arity(kCoopStates, arity) + 1;                   // 64 parents -> 1 digest
+            size_t sz = parents;
+            while (fused < max_fused && sz / arity > kLanesMaxStates) {
+                sz /= arity;
+                fused++;
+            }
+        }
+        if (fused > 1) {
             size_t last_n = parents, span = 0;                    // digests in the last level run; bytes before it
-            for (int j = 1; j < n_levels; j++) {
+            for (int j = 1; j < fused; j++) {
                 span += last_n * 32;
                 last_n /= arity;
             }
             uint8_t *out_all = tree != nullptr ? tree + off : nullptr;
-            // with a tree every level (the root included: it is the tree's last digest) goes through out_all; the two
-            // pointers are __restrict__ in the kernel and must never name the same bytes
-            uint8_t *out_last = tree != nullptr ? nullptr : (last_n == 1 ? root : dst_pp);
-            launch_merkle_coop(arity, src, out_all, out_last, parents, tag, out_idx, n_levels, s);
+            // with a tree every level goes through out_all; the two pointers are __restrict__ in the kernel and must
+            // never name the same bytes
+            uint8_t *out_last = tree != nullptr ? nullptr : dst_pp;
+            launch_merkle_coop(arity, src, out_all, out_last, parents, tag, out_idx, fused, s);
             HIP_TRY(hipGetLastError());
             src = tree != nullptr ? tree + off + span : dst_pp;
             off += span + last_n * 32;
             n = last_n;
+            level += fused;
+        } else {
+            uint8_t *dst = tree != nullptr ? tree + off : (parents == 1 ? root : dst_pp);
+            launch_merkle_any(arity, src, n, dst, tag, out_idx, pad_l, s);
+            HIP_TRY(hipGetLastError());
+            off += parents * 32;
+            src = dst;
+            n = parents;
+            level++;
         }
         to_a = !to_a;
     }
     return HADES252_OK;
 }
 
-int hades252_merkle_root_dev(const void *d_leaves, size_t n_leaves, int arity, void *d_scratch, size_t scratch_bytes,
-                             const uint64_t tag_mont[4], int out_idx, void *d_root, void *stream) {
-    if (d_leaves == nullptr || d_root == nullptr || tag_mont == nullptr || log_arity(n_leaves, arity) < 1 ||
-        out_idx < 0 || out_idx >= 5 || misaligned(d_leaves) || misaligned(d_root))
+int hades252_merkle_root_pad_dev(const void *d_leaves, size_t n_leaves, int arity, void *d_scratch, size_t scratch_bytes,
+                                 const uint64_t tag_mont[4], int out_idx, const void *d_pad, void *d_root, void *stream) {
+    if (d_leaves == nullptr || d_root == nullptr || tag_mont == nullptr || hades252_merkle_depth(n_leaves, arity) < 1 ||
+        out_idx < 0 || out_idx >= 5 || misaligned(d_leaves) || misaligned(d_root) || misaligned(d_pad))
         return HADES252_ERR_INVALID_ARG;
     const size_t need = hades252_merkle_scratch_bytes(n_leaves, arity);
     if (need > 0 && (d_scratch == nullptr || scratch_bytes < need)) return HADES252_ERR_SCRATCH;
     if (need > 0 && misaligned(d_scratch)) return HADES252_ERR_INVALID_ARG;
     uint8_t *buf_a = (uint8_t *)d_scratch;
-    uint8_t *buf_b = need > 0 ? buf_a + (n_leaves / arity) * 32 : nullptr;
+    uint8_t *buf_b = need > 0 ? buf_a + ((n_leaves + arity - 1) / arity) * 32 : nullptr;
     return merkle_run((const uint8_t *)d_leaves, n_leaves, arity, nullptr, buf_a, buf_b, (uint8_t *)d_root,
-                      fr_from_u64(tag_mont), out_idx, (hipStream_t)stream);
+                      fr_from_u64(tag_mont), out_idx, (const uint8_t *)d_pad, (hipStream_t)stream);
+}
+
+int hades252_merkle_root_dev(const void *d_leaves, size_t n_leaves, int arity, void *d_scratch, size_t scratch_bytes,
+                             const uint64_t tag_mont[4], int out_idx, void *d_root, void *stream) {
+    return hades252_merkle_root_pad_dev(d_leaves, n_leaves, arity, d_scratch, scratch_bytes, tag_mont, out_idx, nullptr,
+                                        d_root, stream);
 }
 
 int hades252_merkle4_root_dev(const void *d_leaves, size_t n_leaves, void *d_scratch, size_t scratch_bytes,
@@ -1517,36 +1706,133 @@ int hades252_merkle4_root_dev(const void *d_leaves, size_t n_leaves, void *d_scr
     return hades252_merkle_root_dev(d_leaves, n_leaves, 4, d_scratch, scratch_bytes, tag_mont, out_idx, d_root, stream);
 }
 
-int hades252_merkle_build_dev(const void *d_leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
-                              void *d_tree, void *stream) {
-    if (d_leaves == nullptr || d_tree == nullptr || tag_mont == nullptr || log_arity(n_leaves, arity) < 1 ||
-        out_idx < 0 || out_idx >= 5 || misaligned(d_leaves) || misaligned(d_tree))
+int hades252_merkle_build_pad_dev(const void *d_leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
+                                  const void *d_pad, void *d_tree, void *stream) {
+    if (d_leaves == nullptr || d_tree == nullptr || tag_mont == nullptr || hades252_merkle_depth(n_leaves, arity) < 1 ||
+        out_idx < 0 || out_idx >= 5 || misaligned(d_leaves) || misaligned(d_tree) || misaligned(d_pad))
         return HADES252_ERR_INVALID_ARG;
     uint8_t *tree = (uint8_t *)d_tree;
     uint8_t *root = tree + hades252_merkle_tree_bytes(n_leaves, arity) - 32;
     return merkle_run((const uint8_t *)d_leaves, n_leaves, arity, tree, nullptr, nullptr, root, fr_from_u64(tag_mont),
-                      out_idx, (hipStream_t)stream);
+                      out_idx, (const uint8_t *)d_pad, (hipStream_t)stream);
+}
+
+int hades252_merkle_build_dev(const void *d_leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
+                              void *d_tree, void *stream) {
+    return hades252_merkle_build_pad_dev(d_leaves, n_leaves, arity, tag_mont, out_idx, nullptr, d_tree, stream);
+}
+
+// pad[0] = e0 (the digest standing for a missing leaf), pad[l+1] = perm([tag, pad[l] x arity, 0 ..])[out_idx]: the
+// roots of empty subtrees, level by level -- the usual padding table of an append-only tree
+int hades252_merkle_empty_digests_dev(int arity, int depth, const uint64_t e0_mont[4], const uint64_t tag_mont[4],
+                                      int out_idx, void *d_pad, void *stream) {
+    if (arity < 2 || arity > 4 || depth < 1 || depth > 64 || e0_mont == nullptr || tag_mont == nullptr || d_pad == nullptr ||
+        out_idx < 0 || out_idx >= 5 || misaligned(d_pad))
+        return HADES252_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    uint8_t *pad = (uint8_t *)d_pad;
+    HIP_TRY(hipMemcpyAsync(pad, e0_mont, 32, hipMemcpyHostToDevice, s));
+    const Fr tag = fr_from_u64(tag_mont);
+    for (int l = 0; l + 1 < depth; l++) {
+        // zero children + padding = a parent whose arity children are all pad[l]
+        launch_merkle_lanes(arity, pad, 0, pad + (size_t)(l + 1) * 32, 1, tag, out_idx, pad + (size_t)l * 32, s);
+        HIP_TRY(hipGetLastError());
+    }
+    return HADES252_OK;
+}
+
+int hades252_merkle_open_pad_dev(const void *d_leaves, const void *d_tree, size_t n_leaves, int arity,
+                                 const uint64_t *d_indices, size_t n_queries, const void *d_pad, void *d_paths,
+                                 void *stream) {
+    const int depth = hades252_merkle_depth(n_leaves, arity);
+    if (depth < 1) return HADES252_ERR_INVALID_ARG;
+    if (n_queries == 0) return HADES252_OK;
+    if (d_leaves == nullptr || d_tree == nullptr || d_indices == nullptr || d_paths == nullptr || misaligned(d_leaves) ||
+        misaligned(d_tree) || misaligned(d_paths) || misaligned(d_pad))
+        return HADES252_ERR_INVALID_ARG;
+    const size_t threads = n_queries * (size_t)depth * (arity - 1) * 2;
+    if (threads > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+#define HADES_LAUNCH_OPEN(A)                                                                                            \
+    hipLaunchKernelGGL(k_merkle_open<A>, dim3(blocks_for(threads)), dim3(kBlock), 0, (hipStream_t)stream,             \
+                       (const uint8_t *)d_leaves, (const uint8_t *)d_tree, n_leaves, depth, d_indices, n_queries,     \
+                       (uint8_t *)d_paths, (const uint8_t *)d_pad)
+    switch (arity) {
+        case 2: HADES_LAUNCH_OPEN(2); break;
+        case 3: HADES_LAUNCH_OPEN(3); break;
+        default: HADES_LAUNCH_OPEN(4); break;
+    }
+#undef HADES_LAUNCH_OPEN
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
 }
 
 int hades252_merkle_open_dev(const void *d_leaves, const void *d_tree, size_t n_leaves, int arity,
                              const uint64_t *d_indices, size_t n_queries, void *d_paths, void *stream) {
-    const int depth = log_arity(n_leaves, arity);
-    if (depth < 1) return HADES252_ERR_INVALID_ARG;
-    if (n_queries == 0) return HADES252_OK;
-    if (d_leaves == nullptr || d_tree == nullptr || d_indices == nullptr || d_paths == nullptr || misaligned(d_leaves) ||
-        misaligned(d_tree) || misaligned(d_paths))
+    return hades252_merkle_open_pad_dev(d_leaves, d_tree, n_leaves, arity, d_indices, n_queries, nullptr, d_paths, stream);
+}
+
+// Batched path verification: root_t = the root recomputed from leaf t (d_leaves[t], 32 B), its index and its opening
+// d_paths[t][l][s] (the layout hades252_merkle_open_dev writes).  One query per lane, `depth` permutations each.
+int hades252_merkle_verify_dev(const void *d_leaves, const uint64_t *d_indices, const void *d_paths, size_t n_queries,
+                               int depth, int arity, const uint64_t tag_mont[4], int out_idx, void *d_roots, void *stream) {
+    if (arity < 1 || arity > 4 || depth < 1 || depth > 64 || out_idx < 0 || out_idx >= 5 || tag_mont == nullptr)
         return HADES252_ERR_INVALID_ARG;
-    const size_t threads = n_queries * (size_t)depth * (arity - 1) * 2;
-    if (threads > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
-    if (arity == 4)
-        hipLaunchKernelGGL(k_merkle_open<4>, dim3(blocks_for(threads)), dim3(kBlock), 0, (hipStream_t)stream,
-                           (const uint8_t *)d_leaves, (const uint8_t *)d_tree, n_leaves, depth, d_indices, n_queries,
-                           (uint8_t *)d_paths);
-    else
-        hipLaunchKernelGGL(k_merkle_open<2>, dim3(blocks_for(threads)), dim3(kBlock), 0, (hipStream_t)stream,
-                           (const uint8_t *)d_leaves, (const uint8_t *)d_tree, n_leaves, depth, d_indices, n_queries,
-                           (uint8_t *)d_paths);
+    if (n_queries == 0) return HADES252_OK;
+    if (d_leaves == nullptr || d_indices == nullptr || (d_paths == nullptr && arity > 1) || d_roots == nullptr ||
+        n_queries > kMaxLaunchRecords || misaligned(d_leaves) || misaligned(d_paths) || misaligned(d_roots))
+        return HADES252_ERR_INVALID_ARG;
+    const Fr tag = fr_from_u64(tag_mont);
+#define HADES_LAUNCH_VERIFY(A)                                                                                       \
+    hipLaunchKernelGGL(k_merkle_verify<A>, dim3(blocks_for(n_queries)), dim3(kBlock), lds_for(1), (hipStream_t)stream, \
+                       (const uint8_t *)d_leaves, d_indices, (const uint8_t *)d_paths, n_queries, depth, tag, out_idx,   \
+                       (uint8_t *)d_roots)
+    switch (arity) {
+        case 1: HADES_LAUNCH_VERIFY(1); break;
+        case 2: HADES_LAUNCH_VERIFY(2); break;
+        case 3: HADES_LAUNCH_VERIFY(3); break;
+        default: HADES_LAUNCH_VERIFY(4); break;
+    }
+#undef HADES_LAUNCH_VERIFY
     HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
+// Forest: n_trees independent trees of leaves_per_tree = arity^k leaves each, leaves contiguous tree after tree.  All
+// trees have the same shape, so level l of the whole forest is ONE launch over n_trees * arity^(k-l) parents (a parent
+// never straddles two trees); the roots come out contiguous.  Scratch: two ping-pong level buffers.
+size_t hades252_merkle_forest_scratch_bytes(size_t n_trees, size_t leaves_per_tree, int arity) {
+    const int k = log_arity(leaves_per_tree, arity);
+    if (k < 1 || n_trees == 0) return 0;
+    if (k == 1) return 0;
+    const size_t n1 = n_trees * (leaves_per_tree / arity);
+    return (n1 + n1 / arity) * 32;
+}
+
+int hades252_merkle_forest_dev(const void *d_leaves, size_t n_trees, size_t leaves_per_tree, int arity, void *d_scratch,
+                               size_t scratch_bytes, const uint64_t tag_mont[4], int out_idx, void *d_roots, void *stream) {
+    const int k = log_arity(leaves_per_tree, arity);
+    if (k < 1 || tag_mont == nullptr || out_idx < 0 || out_idx >= 5) return HADES252_ERR_INVALID_ARG;
+    if (n_trees == 0) return HADES252_OK;
+    if (d_leaves == nullptr || d_roots == nullptr || misaligned(d_leaves) || misaligned(d_roots) ||
+        n_trees > kMaxLaunchRecords / leaves_per_tree)
+        return HADES252_ERR_INVALID_ARG;
+    const size_t need = hades252_merkle_forest_scratch_bytes(n_trees, leaves_per_tree, arity);
+    if (need > 0 && (d_scratch == nullptr || scratch_bytes < need)) return HADES252_ERR_SCRATCH;
+    if (need > 0 && misaligned(d_scratch)) return HADES252_ERR_INVALID_ARG;
+    const Fr tag = fr_from_u64(tag_mont);
+    uint8_t *buf_a = (uint8_t *)d_scratch;
+    uint8_t *buf_b = need > 0 ? buf_a + n_trees * (leaves_per_tree / arity) * 32 : nullptr;
+    const uint8_t *src = (const uint8_t *)d_leaves;
+    size_t n = n_trees * leaves_per_tree;
+    bool to_a = true;
+    for (int l = 0; l < k; l++) {
+        uint8_t *dst = l == k - 1 ? (uint8_t *)d_roots : (to_a ? buf_a : buf_b);
+        launch_merkle_any(arity, src, n, dst, tag, out_idx, nullptr, (hipStream_t)stream);
+        HIP_TRY(hipGetLastError());
+        src = dst;
+        n /= arity;
+        to_a = !to_a;
+    }
     return HADES252_OK;
 }
 

@@ -21,13 +21,14 @@ __host__ __device__ constexpr int lds_wave_bytes(int nw) { return kWave * lds_re
 
 // Load the records [rec0, rec0+64) (clipped to n_recs) of `base` into per-lane state.
 // `slab` is this wave's LDS slab (lds_wave_bytes(NW)).  Lanes past the end get zeros.
+// n_scalars = number of 32-byte scalars the buffer holds (a ragged last record reads zeros past it).
 template <int NW>
-__device__ __forceinline__ void wave_load_records(const uint8_t *base, size_t rec0, size_t n_recs,
+__device__ __forceinline__ void wave_load_scalars(const uint8_t *base, size_t rec0, size_t n_scalars,
                                                   uint8_t *slab, Fr (&st)[NW]) {
     constexpr int kLdsRecBytes = lds_rec_bytes(NW);
     const int lane = threadIdx.x & (kWave - 1);
     const size_t rec_bytes = (size_t)NW * 32;
-    const size_t total_chunks = n_recs * (size_t)(2 * NW);
+    const size_t total_chunks = n_scalars * 2;
     const uint4 *g = reinterpret_cast<const uint4 *>(base + rec0 * rec_bytes);
     const size_t chunk0 = rec0 * (size_t)(2 * NW);
 #pragma unroll
@@ -47,6 +48,12 @@ __device__ __forceinline__ void wave_load_records(const uint8_t *base, size_t re
         st[w].l[4] = hi.x; st[w].l[5] = hi.y; st[w].l[6] = hi.z; st[w].l[7] = hi.w;
     }
     __syncthreads();
+}
+
+template <int NW>
+__device__ __forceinline__ void wave_load_records(const uint8_t *base, size_t rec0, size_t n_recs,
+                                                  uint8_t *slab, Fr (&st)[NW]) {
+    wave_load_scalars<NW>(base, rec0, n_recs * (size_t)NW, slab, st);
 }
 
 // Word w of this lane's record -> the wave's slab (no synchronisation; see slab_flush).

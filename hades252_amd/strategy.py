@@ -333,36 +333,64 @@ def _tag_arr(tag_mont: int):
     return (ctypes.c_uint64 * 4)(*[(tag_mont >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)])
 
 
-def _check_arity_pow(n: int, arity: int, what: str) -> int:
-    if arity not in (2, 4):
-        raise ValueError("%s: arity must be 2 or 4" % what)
-    depth, m = 0, n
-    while m > 1 and m % arity == 0:
-        m //= arity
-        depth += 1
-    if m != 1 or depth < 1:
-        raise ValueError("%s: n_leaves must be a power of %d (>= %d)" % (what, arity, arity))
-    return depth
+def merkle_depth(n: int, arity: int, what: str = "merkle") -> int:
+    """Levels above the leaves (n_l = ceil(n_{l-1} / arity)); raises for an invalid shape."""
+    d = _lib.lib().hades252_merkle_depth(n, arity)
+    if d < 1:
+        raise ValueError("%s: need arity 2..4 and at least 2 leaves (got arity %d, %d leaves)" % (what, arity, n))
+    return d
 
 
-def merkle_level(children_t, arity: int, tag_mont: int, out_idx: int = 1):
-    """One tree level: parent = perm([tag, c_0 .. c_{arity-1}, 0 ..])[out_idx]."""
+def merkle_level_sizes(n: int, arity: int):
+    """[n_1, n_2, ..., 1]: nodes per level above the leaves."""
+    out = []
+    while n > 1:
+        n = -(-n // arity)
+        out.append(n)
+    return out
+
+
+def _pad_ptr(pad_t, depth: int, what: str):
+    if pad_t is None:
+        return 0
+    ptr, n, _ = _dev_buffer(pad_t, 32, what)
+    if n < depth:
+        raise ValueError("%s: the padding table needs one digest per level (%d)" % (what, depth))
+    return ptr
+
+
+def merkle_level(children_t, arity: int, tag_mont: int, out_idx: int = 1, pad=None):
+    """One tree level: parent = perm([tag, c_0 .. c_{arity-1}, 0 ..])[out_idx], arity 1..4.  A ragged level (child
+    count not a multiple of the arity) takes ``pad`` (one 32-byte digest on the device; None = zero) for the missing
+    children."""
     import torch
-    if arity not in (2, 4):
-        raise ValueError("merkle_level: arity must be 2 or 4")
-    ptr, n, dev = _dev_buffer(children_t, 32 * arity, "merkle_level")
+    if arity not in (1, 2, 3, 4):
+        raise ValueError("merkle_level: arity must be 1..4")
+    ptr, n_children, dev = _dev_buffer(children_t, 32, "merkle_level")
+    n = -(-n_children // arity)
     parents = torch.empty((n, 4), dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.lib().hades252_merkle_level_dev(ptr, parents.data_ptr(), n, arity, _tag_arr(tag_mont), out_idx,
-                                                   _stream_ptr(dev)), "merkle_level")
+        check(_lib.lib().hades252_merkle_level_pad_dev(ptr, n_children, parents.data_ptr(), arity, _tag_arr(tag_mont),
+                                                       out_idx, _pad_ptr(pad, 1, "merkle_level"), _stream_ptr(dev)),
+              "merkle_level")
     return parents
 
 
-def merkle_root(leaves_t, arity: int, tag_mont: int, out_idx: int = 1, scratch=None):
-    """Root of the arity-`arity` tree over ``leaves_t`` (n_leaves x 32 B, n_leaves a power of arity)."""
+def merkle_empty_digests(arity: int, depth: int, e0_mont: int, tag_mont: int, out_idx: int = 1, device="cuda"):
+    """The padding table of empty subtrees: [depth, 4] int64 -- pad[0] = e0, pad[l+1] = parent of `arity` x pad[l]."""
+    import torch
+    pad = torch.empty((depth, 4), dtype=torch.int64, device=device)
+    with torch.cuda.device(pad.device):
+        check(_lib.lib().hades252_merkle_empty_digests_dev(arity, depth, _tag_arr(e0_mont), _tag_arr(tag_mont), out_idx,
+                                                           pad.data_ptr(), _stream_ptr(pad.device)), "merkle_empty_digests")
+    return pad
+
+
+def merkle_root(leaves_t, arity: int, tag_mont: int, out_idx: int = 1, scratch=None, pad=None):
+    """Root of the arity-`arity` tree over ``leaves_t`` (n_leaves x 32 B; any n_leaves >= 2, arity 2..4)."""
     import torch
     ptr, n, dev = _dev_buffer(leaves_t, 32, "merkle_root")
-    _check_arity_pow(n, arity, "merkle_root")
+    depth = merkle_depth(n, arity, "merkle_root")
     need = _lib.lib().hades252_merkle_scratch_bytes(n, arity)
     if scratch is None:
         scratch = torch.empty(max(need // 8, 2), dtype=torch.int64, device=dev)
@@ -370,40 +398,76 @@ def merkle_root(leaves_t, arity: int, tag_mont: int, out_idx: int = 1, scratch=N
     sbytes = scratch.numel() * scratch.element_size()
     root = torch.empty(4, dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.lib().hades252_merkle_root_dev(ptr, n, arity, sptr, sbytes, _tag_arr(tag_mont), out_idx,
-                                                  root.data_ptr(), _stream_ptr(dev)), "merkle_root")
+        check(_lib.lib().hades252_merkle_root_pad_dev(ptr, n, arity, sptr, sbytes, _tag_arr(tag_mont), out_idx,
+                                                      _pad_ptr(pad, depth, "merkle_root"), root.data_ptr(),
+                                                      _stream_ptr(dev)), "merkle_root")
     return root
 
 
-def merkle_build(leaves_t, arity: int, tag_mont: int, out_idx: int = 1):
-    """Every level of the tree: [(n-1)/(arity-1), 4] int64 -- level 1 first, the root last."""
+def merkle_build(leaves_t, arity: int, tag_mont: int, out_idx: int = 1, pad=None):
+    """Every level of the tree: [n_1 + n_2 + ... + 1, 4] int64 -- level 1 first, the root last."""
     import torch
     ptr, n, dev = _dev_buffer(leaves_t, 32, "merkle_build")
-    _check_arity_pow(n, arity, "merkle_build")
-    tree = torch.empty(((n - 1) // (arity - 1), 4), dtype=torch.int64, device=dev)
+    depth = merkle_depth(n, arity, "merkle_build")
+    tree = torch.empty((sum(merkle_level_sizes(n, arity)), 4), dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.lib().hades252_merkle_build_dev(ptr, n, arity, _tag_arr(tag_mont), out_idx, tree.data_ptr(),
-                                                   _stream_ptr(dev)), "merkle_build")
+        check(_lib.lib().hades252_merkle_build_pad_dev(ptr, n, arity, _tag_arr(tag_mont), out_idx,
+                                                       _pad_ptr(pad, depth, "merkle_build"), tree.data_ptr(),
+                                                       _stream_ptr(dev)), "merkle_build")
     return tree
 
 
-def merkle_open(leaves_t, tree_t, arity: int, indices_t):
+def merkle_open(leaves_t, tree_t, arity: int, indices_t, pad=None):
     """Authentication paths: [n_queries, depth, arity-1, 4] int64 (siblings in child order, the path node's
-    own position (index // arity^l) % arity skipped)."""
+    own position (index // arity^l) % arity skipped; positions past the end of a level read pad[l])."""
     import torch
     ptr, n, dev = _dev_buffer(leaves_t, 32, "merkle_open")
-    depth = _check_arity_pow(n, arity, "merkle_open")
+    depth = merkle_depth(n, arity, "merkle_open")
     tptr, nt, _ = _dev_buffer(tree_t, 32, "merkle_open")
-    if nt != (n - 1) // (arity - 1):
+    if nt != sum(merkle_level_sizes(n, arity)):
         raise ValueError("merkle_open: tree buffer does not belong to %d leaves" % n)
     iptr, nq, _ = _dev_buffer(indices_t, 8, "merkle_open")
     if nq and int(indices_t.max().item()) >= n:
         raise IndexError("merkle_open: leaf index out of range")
     paths = torch.empty((nq, depth, arity - 1, 4), dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.lib().hades252_merkle_open_dev(ptr, tptr, n, arity, iptr, nq, paths.data_ptr(), _stream_ptr(dev)),
-              "merkle_open")
+        check(_lib.lib().hades252_merkle_open_pad_dev(ptr, tptr, n, arity, iptr, nq, _pad_ptr(pad, depth, "merkle_open"),
+                                                      paths.data_ptr(), _stream_ptr(dev)), "merkle_open")
     return paths
+
+
+def merkle_verify(leaf_values_t, indices_t, paths_t, arity: int, tag_mont: int, out_idx: int = 1):
+    """Roots recomputed from (leaf value, index, opening) per query: [n_queries, 4] int64."""
+    import torch
+    lptr, nq, dev = _dev_buffer(leaf_values_t, 32, "merkle_verify")
+    iptr, nq2, _ = _dev_buffer(indices_t, 8, "merkle_verify")
+    if nq2 != nq or paths_t.shape[0] != nq:
+        raise ValueError("merkle_verify: leaves, indices and paths differ in count")
+    depth = int(paths_t.shape[1])
+    pptr = paths_t.data_ptr() if paths_t.numel() else 0
+    roots = torch.empty((nq, 4), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_merkle_verify_dev(lptr, iptr, pptr, nq, depth, arity, _tag_arr(tag_mont), out_idx,
+                                                    roots.data_ptr(), _stream_ptr(dev)), "merkle_verify")
+    return roots
+
+
+def merkle_forest(leaves_t, n_trees: int, arity: int, tag_mont: int, out_idx: int = 1, scratch=None):
+    """Roots of n_trees equal trees (leaves contiguous, tree after tree; leaves per tree a power of the arity)."""
+    import torch
+    ptr, n, dev = _dev_buffer(leaves_t, 32, "merkle_forest")
+    if n_trees <= 0 or n % n_trees:
+        raise ValueError("merkle_forest: %d leaves do not split into %d trees" % (n, n_trees))
+    per = n // n_trees
+    need = _lib.lib().hades252_merkle_forest_scratch_bytes(n_trees, per, arity)
+    if scratch is None:
+        scratch = torch.empty(max(need // 8, 2), dtype=torch.int64, device=dev)
+    roots = torch.empty((n_trees, 4), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_merkle_forest_dev(ptr, n_trees, per, arity, scratch.data_ptr(),
+                                                    scratch.numel() * scratch.element_size(), _tag_arr(tag_mont), out_idx,
+                                                    roots.data_ptr(), _stream_ptr(dev)), "merkle_forest")
+    return roots
 
 
 def merkle4_level(children_t, tag_mont: int, out_idx: int = 1):

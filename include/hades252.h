@@ -61,7 +61,10 @@ extern "C" {
 #define HADES252_KERNEL_LITERAL 1 /* the reference's round structure, 1972 Montgomery products */
 #define HADES252_KERNEL_FAST 2    /* scale-tracked small-integer MDS formulation, one state per lane */
 #define HADES252_KERNEL_COOP 3    /* same arithmetic, the five words of a state on five waves: less than half the
-                                     latency, ~2/3 of the throughput; DEFAULT picks it for n_perms <= 16384 */
+                                     latency, ~2/3 of the throughput; DEFAULT picks it for 1024 < n_perms <= 16384 */
+#define HADES252_KERNEL_LANES 4   /* one state per wave, every field element spread over a 16-lane row (products by the
+                                     row, lane-parallel carries): the lowest latency for ONE permutation -- the
+                                     reference's own call shape (README.md:60-61); DEFAULT picks it for n_perms <= 1024 */
 
 /* ---- meta --------------------------------------------------------------------------- */
 /* Strategy::rounds() (src/strategies.rs:160-162): TOTAL_FULL_ROUNDS + PARTIAL_ROUNDS = 67 */
@@ -163,29 +166,65 @@ int hades252_from_bytes_dev(const void *d_bytes, void *d_limbs, size_t n_scalars
 int hades252_to_bytes_dev(const void *d_limbs, void *d_bytes, size_t n_scalars, void *stream);
 
 /* ---- Poseidon Merkle trees over the permutation (caller shape of dusk-poseidon, README.md:9) -------
- * parent = perm([tag, child_0 .. child_{arity-1}, 0 ..])[out_idx]; tag in Montgomery limbs; arity 2 or 4.
- * The external convention for arity 4 is tag = 2^4 - 1 = 15, out_idx = 1 (NOT pinned by the reference: both
- * are parameters).  n_leaves must be a power of `arity`, >= arity.  Digests are 32 B Montgomery limbs. */
+ * parent = perm([tag, child_0 .. child_{arity-1}, 0 ..])[out_idx]; tag in Montgomery limbs.  The external convention
+ * for arity 4 is tag = 2^4 - 1 = 15, out_idx = 1 (NOT pinned by the reference: both are parameters).  Digests are 32 B
+ * Montgomery limbs.
+ * Shapes: arity 2, 3 or 4 for trees (1 .. 4 for single levels and path verification); ANY number of leaves >= 2.
+ *   Level l (l = 0: the leaves) has n_l nodes, n_{l+1} = ceil(n_l / arity), down to one root: hades252_merkle_depth
+ *   levels above the leaves.  Padding rule: a child position past the end of level l holds pad[l], a table of `depth`
+ *   digests in DEVICE memory the caller supplies to the _pad entry points (NULL = the zero scalar at every level);
+ *   hades252_merkle_empty_digests_dev fills it with the roots of empty subtrees (pad[0] = e0, pad[l+1] = the parent of
+ *   `arity` copies of pad[l]) -- the table an append-only tree uses.  Trees whose leaf count is a power of the arity
+ *   never touch the table. */
+int hades252_merkle_depth(size_t n_leaves, int arity);      /* -1: invalid (arity not 2..4, or fewer than 2 leaves) */
+/* One level.  _dev: n_parents full parents from arity * n_parents children (arity 1 .. 4);
+ * _pad_dev: n_children children -> ceil(n_children / arity) parents, missing children = the digest at d_pad (32 B). */
 int hades252_merkle_level_dev(const void *d_children, void *d_parents, size_t n_parents, int arity,
                               const uint64_t tag_mont[4], int out_idx, void *stream);
+int hades252_merkle_level_pad_dev(const void *d_children, size_t n_children, void *d_parents, int arity,
+                                  const uint64_t tag_mont[4], int out_idx, const void *d_pad, void *stream);
 /* Root only.  d_scratch needs hades252_merkle_scratch_bytes(n_leaves, arity) bytes (0 for a one-level tree;
- * d_scratch may then be NULL); the root (32 B) is written to d_root.  Large levels run one parent per lane;
- * the last <= 65 536 nodes (arity 4) run fused inside CUs: 64 parents per workgroup through four levels in LDS. */
+ * d_scratch may then be NULL); the root (32 B) is written to d_root.  Levels of more than 16 384 parents run one
+ * parent per lane; full levels of 1 025 .. 16 384 parents five waves per parent (arity 2 / 4 and power-of-arity levels:
+ * 64 parents per workgroup through several levels in LDS); levels of at most 1 024 parents one parent per wave. */
 size_t hades252_merkle_scratch_bytes(size_t n_leaves, int arity);
 int hades252_merkle_root_dev(const void *d_leaves, size_t n_leaves, int arity, void *d_scratch, size_t scratch_bytes,
                              const uint64_t tag_mont[4], int out_idx, void *d_root, void *stream);
-/* Whole tree, every level kept: d_tree (hades252_merkle_tree_bytes = 32 * (n_leaves - 1) / (arity - 1) bytes)
- * receives level 1 (n/arity digests), then level 2, ... ; the root is its last 32 bytes. */
+int hades252_merkle_root_pad_dev(const void *d_leaves, size_t n_leaves, int arity, void *d_scratch, size_t scratch_bytes,
+                                 const uint64_t tag_mont[4], int out_idx, const void *d_pad, void *d_root, void *stream);
+/* Whole tree, every level kept: d_tree (hades252_merkle_tree_bytes = 32 * (n_1 + n_2 + ... + 1) bytes; for
+ * n_leaves = arity^k that is 32 * (n_leaves - 1) / (arity - 1)) receives level 1, then level 2, ... ; the root is its
+ * last 32 bytes.  0 = invalid shape. */
 size_t hades252_merkle_tree_bytes(size_t n_leaves, int arity);
 int hades252_merkle_build_dev(const void *d_leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
                               void *d_tree, void *stream);
+int hades252_merkle_build_pad_dev(const void *d_leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
+                                  const void *d_pad, void *d_tree, void *stream);
+/* The padding table of empty subtrees: d_pad[0] = e0, d_pad[l+1] = parent of `arity` copies of d_pad[l], l < depth - 1. */
+int hades252_merkle_empty_digests_dev(int arity, int depth, const uint64_t e0_mont[4], const uint64_t tag_mont[4],
+                                      int out_idx, void *d_pad, void *stream);
 /* Openings (authentication paths) from a built tree: for query t with leaf index d_indices[t] (device u64) and
  * level l = 0 .. depth-1, the arity-1 siblings of the path node, in child order with the node's own position
- * (index / arity^l) % arity skipped: d_paths[t][l][s], 32 B each, depth * (arity-1) * 32 bytes per query.
- * An index >= n_leaves yields an all-zero path (nothing outside the tree is read). */
+ * (index / arity^l) % arity skipped: d_paths[t][l][s], 32 B each, depth * (arity-1) * 32 bytes per query; a sibling
+ * position past the end of its level reads pad[l].  An index >= n_leaves yields an all-zero path (nothing outside the
+ * tree is read). */
 int hades252_merkle_open_dev(const void *d_leaves, const void *d_tree, size_t n_leaves, int arity,
                              const uint64_t *d_indices, size_t n_queries, void *d_paths, void *stream);
-/* arity-4 forms (BASELINE config 4) */
+int hades252_merkle_open_pad_dev(const void *d_leaves, const void *d_tree, size_t n_leaves, int arity,
+                                 const uint64_t *d_indices, size_t n_queries, const void *d_pad, void *d_paths,
+                                 void *stream);
+/* Batched path verification: d_roots[t] (32 B) = the root recomputed from leaf value d_leaves[t] (32 B each, query
+ * order), its index d_indices[t] and its opening d_paths[t] (the layout above); the caller compares with the root it
+ * trusts.  One query per lane, `depth` permutations each; arity 1 .. 4. */
+int hades252_merkle_verify_dev(const void *d_leaves, const uint64_t *d_indices, const void *d_paths, size_t n_queries,
+                               int depth, int arity, const uint64_t tag_mont[4], int out_idx, void *d_roots, void *stream);
+/* Forest: n_trees independent trees of leaves_per_tree = arity^k leaves each (leaves contiguous, tree after tree); level l
+ * of all trees is one launch; d_roots receives n_trees roots.  Scratch: hades252_merkle_forest_scratch_bytes. */
+size_t hades252_merkle_forest_scratch_bytes(size_t n_trees, size_t leaves_per_tree, int arity);
+int hades252_merkle_forest_dev(const void *d_leaves, size_t n_trees, size_t leaves_per_tree, int arity, void *d_scratch,
+                               size_t scratch_bytes, const uint64_t tag_mont[4], int out_idx, void *d_roots, void *stream);
+/* arity-4 forms (BASELINE config 4).  hades252_merkle4_scratch_bytes is 0 both for a one-level tree (4 leaves need no
+ * scratch) and for an invalid shape: hades252_merkle_depth(n, 4) < 1 tells the second from the first. */
 int hades252_merkle4_level_dev(const void *d_children, void *d_parents, size_t n_parents,
                                const uint64_t tag_mont[4], int out_idx, void *stream);
 size_t hades252_merkle4_scratch_bytes(size_t n_leaves);

@@ -150,19 +150,36 @@ class Oracle:
                                          ctypes.c_int(out_idx), ctypes.c_int(threads or self.ncpu))
         return out
 
-    def merkle_tree(self, leaves, arity, tag_mont, out_idx=1):
-        """All levels above the leaves, level 1 first (the layout of hades252_merkle_build_dev), as a list."""
-        levels, cur = [], np.ascontiguousarray(leaves, dtype=np.uint64)
+    def merkle_level_pad(self, children, arity, tag_mont, out_idx=1, pad=None, threads=None):
+        """A ragged level: children padded up to a multiple of the arity with the digest `pad` (4 limbs; None = zero)."""
+        ch = np.ascontiguousarray(children, dtype=np.uint64).reshape(-1, 4)
+        miss = (-ch.shape[0]) % arity
+        if miss:
+            fill = np.zeros(4, dtype=np.uint64) if pad is None else np.ascontiguousarray(pad, dtype=np.uint64).reshape(4)
+            ch = np.concatenate([ch, np.tile(fill, (miss, 1))])
+        return self.merkle_level(ch.reshape(-1), arity, tag_mont, out_idx, threads)
+
+    def merkle_tree(self, leaves, arity, tag_mont, out_idx=1, pad=None):
+        """All levels above the leaves, level 1 first (the layout of hades252_merkle_build_dev), as a list.  Any number
+        of leaves: level l's missing children take pad[l] (rows of 4 limbs; None = zeros)."""
+        levels, cur, l = [], np.ascontiguousarray(leaves, dtype=np.uint64), 0
         while cur.size > 4:
-            cur = self.merkle_level(cur, arity, tag_mont, out_idx)
+            cur = self.merkle_level_pad(cur, arity, tag_mont, out_idx, None if pad is None else pad[l])
             levels.append(cur)
+            l += 1
         return levels
+
+    def merkle_empty_digests(self, arity, depth, e0_mont, tag_mont, out_idx=1):
+        pad = [np.array(limbs_of(e0_mont), dtype=np.uint64)]
+        for _ in range(depth - 1):
+            pad.append(self.merkle_level(np.tile(pad[-1], arity), arity, tag_mont, out_idx, threads=1))
+        return np.stack(pad)
 
     def merkle_verify_path(self, leaf, index, path, arity, tag_mont, out_idx=1):
         """Recompute the root from a leaf (4 limbs), its index and its opening path[l][s] (siblings in child
         order, own position skipped).  Returns the root's 4 limbs."""
         node = np.ascontiguousarray(leaf, dtype=np.uint64).reshape(4)
-        path = np.ascontiguousarray(path, dtype=np.uint64).reshape(-1, arity - 1, 4)
+        path = np.ascontiguousarray(path, dtype=np.uint64).reshape(-1, max(arity - 1, 0), 4)
         for l in range(path.shape[0]):
             pos = index % arity
             sib = list(path[l])

@@ -42,11 +42,19 @@ def test_meta_calls_without_gpu(hades_lib):
     # NULL with n > 0 is an argument error, not a crash
     assert hades_lib.hades252_perm_batch_dev(None, 4, None) == -1
     assert hades_lib.hades252_merkle4_scratch_bytes(16) == 4 * 32 + 32
-    assert hades_lib.hades252_merkle4_scratch_bytes(8) == 0
-    assert hades_lib.hades252_merkle4_scratch_bytes(4) == 0          # one level: no scratch needed
+    assert hades_lib.hades252_merkle4_scratch_bytes(4) == 0          # one level: no scratch needed (a valid shape:
+    assert hades_lib.hades252_merkle_depth(4, 4) == 1                # depth tells valid from invalid)
     assert hades_lib.hades252_merkle_scratch_bytes(8, 2) == 4 * 32 + 2 * 32
     assert hades_lib.hades252_merkle_tree_bytes(16, 4) == 5 * 32 and hades_lib.hades252_merkle_tree_bytes(8, 2) == 7 * 32
-    assert hades_lib.hades252_merkle_tree_bytes(12, 4) == 0 and hades_lib.hades252_merkle_tree_bytes(16, 3) == 0
+    # any leaf count >= 2, arity 2..4: n_l = ceil(n_{l-1} / arity)
+    assert hades_lib.hades252_merkle_depth(12, 4) == 2 and hades_lib.hades252_merkle_tree_bytes(12, 4) == (3 + 1) * 32
+    assert hades_lib.hades252_merkle_depth(16, 3) == 3 and hades_lib.hades252_merkle_tree_bytes(16, 3) == (6 + 2 + 1) * 32
+    assert hades_lib.hades252_merkle4_scratch_bytes(8) == (2 + 1) * 32
+    assert hades_lib.hades252_merkle_depth(3 ** 9, 3) == 9 and hades_lib.hades252_merkle_depth(4 ** 7 * 3, 4) == 8
+    for n, a in ((1, 4), (0, 2), (16, 5), (16, 1), (16, 0)):
+        assert hades_lib.hades252_merkle_depth(n, a) == -1 and hades_lib.hades252_merkle_tree_bytes(n, a) == 0
+    assert hades_lib.hades252_merkle_forest_scratch_bytes(10, 64, 4) == (160 + 40) * 32
+    assert hades_lib.hades252_merkle_forest_scratch_bytes(10, 48, 4) == 0        # trees of a forest: powers of the arity
 
 
 def test_no_cpu_fallback_in_product():

@@ -68,9 +68,26 @@ def test_perm_fast_instruction_mix(device_asm):
 
 
 @pytest.mark.parametrize("needle", ["k_perm_fast", "k_sponge", "k_merkle_level_fast", "k_merkle_coop", "k_perm_coop",
-                                    "k_perm_trace_fast", "k_perm_witness", "k_fr_op"])
+                                    "k_perm_trace_fast", "k_perm_witness", "k_fr_op", "k_perm_lanes", "k_merkle_lanes"])
 def test_hot_kernels_have_no_scratch(device_asm, needle):
     _, res = device_asm
     for name in find(res, needle):
         assert res[name]["ScratchSize"] == 0, (name, res[name])
         assert res[name]["VGPRs Spill"] == 0, (name, res[name])      # (SGPR spills go to VGPR lanes, not memory)
+
+
+def test_perm_lanes_instruction_mix(device_asm):
+    """The lane-split kernel's latency IS its instruction count (one wave issues one instruction per ~4.4 cycles): a
+    product is 28 multiply-adds (9 + 9 + 9 + the column-16 one) and ~45 DPP moves; a partial round runs 3 products, a
+    full round 6.  A toolchain change that splits the 64-bit multiply-adds or doubles the DPP traffic fails here."""
+    bodies, res = device_asm
+    (name,) = find(bodies, "k_perm_lanes")
+    body = bodies[name]
+    umads = len(re.findall(r"\bv_mad_u64_u32\b", body))
+    dpp = len(re.findall(r"\bv_mov_b32_dpp\b", body))
+    nops = len(re.findall(r"\bs_nop\b", body))
+    # 9 products in the two round bodies x 28 + the two linear-layer rows (6 each) + the per-lane final product
+    assert 9 * 28 <= umads <= 9 * 28 + 40, umads
+    assert dpp <= 9 * 45 + 30, dpp
+    assert nops <= 130, "%d s_nop: the hand-made interleaving of the two S-boxes of a full round got lost?" % nops
+    assert res[name]["VGPRs"] <= 96, res[name]

@@ -383,3 +383,181 @@ def test_other_loader_reading_is_one_flag_away(monkeypatch):
         assert got == [S.to_mont(v) for v in S.perm(vals)]
     finally:
         S.set_loader("from_raw")
+
+
+# ---------------------------------------------------------------------------------------------
+# lane-split schedule (csrc/hades_lanes.cuh): one field element on the 16 lanes of a DPP row, all-unsigned arithmetic.
+# The model keeps a row as a list of 16 lane values and replays every statement of lane_mont_mul_n / lane_mds_row /
+# lanes_perm with the machine-word bounds asserted (u64 columns, u32 limbs).
+# ---------------------------------------------------------------------------------------------
+U64, U32 = 1 << 64, 1 << 32
+PINV29 = D.to_limbs29((-pow(P, -1, D.RP)) % D.RP)
+LANE_IN_MAX = (1 << 30) + 1            # operand limb bound of the lane product
+
+
+def row_shr(v, n):
+    return [v[k - n] if k - n >= 0 else 0 for k in range(16)]
+
+
+def row_shl(v, n):
+    return [v[k + n] if k + n <= 15 else 0 for k in range(16)]
+
+
+def row_bcast(v, n):
+    return [v[n]] * 16
+
+
+def u64(x):
+    assert 0 <= x < U64, "unsigned 64-bit column overflow"
+    return x
+
+
+def u32(x):
+    assert 0 <= x < U32, "unsigned 32-bit overflow"
+    return x
+
+
+def carry_split(acc):
+    """carry_split of hades_lanes.cuh -> (limbs, c16, c17)."""
+    lo = [a & MASK for a in acc]
+    mid = [(a >> LB) & MASK for a in acc]
+    tp = [a >> 58 for a in acc]
+    u = [u32(x + y) for x, y in zip(mid, row_shr(tp, 1))]
+    t = [u32(x + y) for x, y in zip(lo, row_shr(u, 1))]
+    assert all(x < (1 << 30) + 64 for x in t)
+    return t, u, tp
+
+
+def carry_light(t):
+    h = [x >> LB for x in t]
+    return [u32((x & MASK) + y) for x, y in zip(t, row_shr(h, 1))], h
+
+
+def lane_val(v):
+    assert all(x == 0 for x in v[NL:]), "lanes 9..15 must be zero"
+    return val(v[:NL])
+
+
+def lane_mont_mul(a, b):
+    """lane_mont_mul_n<1> of hades_lanes.cuh: a, b = 16-lane rows (limb k in lane k); returns the row of a value
+    == a*b/2^261 (mod p) in [0, a*b/2^261 + 2.01 p)."""
+    assert all(0 <= x <= LANE_IN_MAX for x in a + b) and lane_val(a) < (1 << 258) and lane_val(b) < (1 << 258)
+    acc = [0] * 16
+    for i in range(NL):
+        ai, bi = row_bcast(a, i), row_shr(b, i)
+        acc = [u64(c + x * y) for c, x, y in zip(acc, ai, bi)]
+    top = [u64(x * y) for x, y in zip(row_bcast(a, NL - 1), row_shl(b, 8))]
+    assert all(x == 0 for x in top[1:])
+    t, c16a, c17a = carry_split(acc)
+    assert val(t) + ((top[0] + c16a[15]) << (LB * 16)) + (c17a[15] << (LB * 17)) == lane_val(a) * lane_val(b)
+    acc = [0] * 16
+    for i in range(NL):
+        acc = [u64(c + x * PINV29[i]) for c, x in zip(acc, row_shr(t, i))]
+    m, _, _ = carry_split(acc)
+    m = [x if k < NL else 0 for k, x in enumerate(m)]
+    assert (val(m[:NL]) - val(t[:NL]) * val(PINV29)) % D.RP == 0          # M == T p' (mod 2^261)
+    acc = list(t)
+    for i in range(NL):
+        acc = [u64(c + x * P29[i]) for c, x in zip(acc, row_shr(m, i))]
+    top = [u64(x + y * P29[NL - 1]) for x, y in zip(top, row_shl(m, 8))]
+    w1, c16b, c17b = carry_split(acc)
+    assert c17a[15] == 0 and c17b[15] == 0, "column 15 never reaches bit 58 (hades_lanes.cuh drops c17)"
+    w, c16c = carry_light(w1)
+    assert all(x <= (1 << LB) + 2 for x in w)
+    low = val(w[:NL])
+    assert low in (0, D.RP), "the low nine limbs cancel to 0 or 2^261"
+    assert (low == 0) == (w[NL - 1] == 0)
+    z = [min(w[k], 1) if k == NL - 1 else 0 for k in range(16)]
+    w = [u32(x + y) for x, y in zip(w, row_shr(z, 1))]
+    top = [u64(x + y) for x, y in zip(top, row_shl([u32(p + q + r) for p, q, r in zip(c16a, c16b, c16c)], 15))]
+    assert all(x == 0 for x in top[1:])
+    r7 = [x & MASK for x in top]
+    r8 = [u32(x >> LB) for x in top]
+    out = [u32(x + y + zz) for x, y, zz in zip(row_shl(w, 9), row_shr(r7, 7), row_shr(r8, 8))]
+    ab = lane_val(a) * lane_val(b)
+    r = lane_val(out)
+    assert r * D.RP == ab + val(m[:NL]) * P, "R = (ab + M p) / 2^261 exactly"
+    assert r < ab // D.RP + 2 * P + (P >> 20) and all(x <= (1 << LB) + 2 for x in out) and out[NL - 1] < (1 << 26)
+    return out
+
+
+def lane_sbox(v):
+    v2 = lane_mont_mul(v, v)
+    v4 = lane_mont_mul(v2, v2)
+    return lane_mont_mul(v, v4)
+
+
+def lane_mds_row(c, xs):
+    """lane_mds_row of hades_lanes.cuh: (sum_j c_j x_j + m p) / 2^29, m = -Y_0 mod 2^29."""
+    y = [0] * 16
+    for j in range(5):
+        y = [u64(a + x * c[j]) for a, x in zip(y, xs[j])]
+    m = ((0 - y[0]) % U32) & MASK
+    pk = P29 + [0] * 7
+    y = [u64(a + m * q) for a, q in zip(y, pk)]
+    assert all(a < (1 << 59) for a in y) and y[0] & MASK == 0
+    t = [u32((a & MASK) + b) for a, b in zip(y, row_shr([(a >> LB) & (U32 - 1) for a in y], 1))]
+    w, _ = carry_light(t)
+    assert w[0] == 0
+    out = row_shl(w, 1)
+    assert lane_val(out) << LB == sum(c[j] * lane_val(xs[j]) for j in range(5)) + m * P
+    assert all(x <= (1 << LB) + 2 for x in out)
+    return out
+
+
+def lanes_perm_model(mont_vals):
+    """Limb-exact replay of lanes_perm (hades_lanes.cuh): the coop schedule on rows, plain-limb round constants."""
+    co = D.coop_schedule()
+    row_of = lambda v: D.to_limbs29(v) + [0] * 7
+    st = [row_of(v) for v in mont_vals]
+    for r in range(D.ROUNDS):
+        full = D.is_full_round(r)
+        x = [[u32(a + b) for a, b in zip(st[w], row_of(co["a"][r][w]))] for w in range(5)]
+        if full:
+            nxt = [lane_sbox(x[w]) for w in range(5)]
+        else:
+            assert all(co["a"][r][w] == 0 for w in range(4))
+            g = row_of(co["g"][r])
+            nxt = [lane_mont_mul(x[w], g) for w in range(4)] + [lane_sbox(x[4])]
+        st = [lane_mds_row(D.MDS_SMALL[i], nxt) for i in range(5)]
+    return [finalize_model(x[:NL], co["final_f"]) for x in st]
+
+
+def test_lanes_model_matches_spec_oracle():
+    rng = random.Random(43)
+    cases = [[1] * 5, [0] * 5, [P - 1] * 5, [15, 1, 2, 3, 4]]
+    cases += [[rng.choice(EDGE) for _ in range(5)] for _ in range(3)]
+    cases += [[rng.randrange(P) for _ in range(5)] for _ in range(3)]
+    for vals in cases:
+        got = lanes_perm_model([S.to_mont(v) for v in vals])
+        assert got == [S.to_mont(v) for v in S.perm(vals)]
+
+
+def test_lanes_product_bounds_adversarial():
+    """Operand limbs at the lazy maximum 2^30 + 1 (both operands: the square of an S-box input after its round key),
+    all-ones, sparse and tiny operands: no u64 / u32 overflow, exact division, zero-or-2^261 low part."""
+    rng = random.Random(47)
+    top = (1 << 25) - 1                                   # value < 2^258 (the kernel's values stay below 2^257)
+    pats = [[LANE_IN_MAX] * (NL - 1) + [top], [MASK] * (NL - 1) + [top], [0] * NL, [1] + [0] * (NL - 1),
+            [0] * (NL - 1) + [top], [LANE_IN_MAX, 0] * 4 + [top], [(1 << LB) + 2] * (NL - 1) + [top]]
+    pats += [[rng.randrange(LANE_IN_MAX + 1) for _ in range(NL - 1)] + [rng.randrange(top)] for _ in range(40)]
+    rows = [p + [0] * 7 for p in pats]
+    for a in rows:
+        for b in rows[:9]:
+            r = lane_mont_mul(a, b)
+            assert lane_val(r) % P == lane_val(a) * lane_val(b) * pow(D.RP, -1, P) % P
+    # linear layer at its maxima
+    big = [(1 << LB) + 2] * (NL - 1) + [(1 << 26) - 1] + [0] * 7          # the result bound of a product
+    for i in range(5):
+        lane_mds_row(D.MDS_SMALL[i], [big] * 5)
+        lane_mds_row(D.MDS_SMALL[i], [rows[0]] * 5)          # even straight after a round key
+
+
+def test_lanes_tables_are_the_coop_schedule_with_plain_limbs():
+    text = open(os.path.join(ROOT, "hades252_amd", "csrc", "hades_constants.inc")).read()
+    assert "#define HADES_LANES_ROUND_INIT" in text and "#define HADES_NEG_PINV29" in text
+    co = D.coop_schedule()
+    first = [x for v in co["a"][0] for x in D.to_limbs29(v)] + D.to_limbs29(co["g"][0]) + [0] * 10
+    assert "{" + ", ".join("%d" % x for x in first) + "}" in text
+    assert "{" + ", ".join("%d" % x for x in PINV29) + "}" in text
+    assert (val(PINV29) * P + 1) % D.RP == 0

@@ -15,7 +15,8 @@ from oracle_lib import P, R, limbs_of, int_of, digest_ref  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [1, 2, 3]   # HADES252_KERNEL_LITERAL, _FAST (one state per lane), _COOP (five waves per state)
+KERNELS = [1, 2, 3, 4]   # HADES252_KERNEL_LITERAL, _FAST (one state per lane), _COOP (five waves per state), _LANES (one
+                         # state per wave, elements spread over 16-lane rows)
 
 
 @pytest.fixture(scope="module")
@@ -279,8 +280,11 @@ def test_merkle(torch_cuda, H, oracle, kat):
     leaves = H.gen_b(n, "cuda")
     root = H.merkle4_root(leaves, tag, 1)
     assert (to_host(root) == oracle.merkle4_root(oracle.gen_b(0, n), tag, 1)).all()
+    # 8 leaves are a valid (ragged) arity-4 tree since round 3: two parents, then a root over [p0, p1, 0, 0]
+    l8 = oracle.gen_b(0, 8)
+    assert (to_host(H.merkle4_root(H.gen_b(8, "cuda"), tag, 1)) == oracle.merkle_tree(l8, 4, tag, 1)[-1]).all()
     with pytest.raises(ValueError):
-        H.merkle4_root(H.gen_b(8, "cuda"), tag, 1)
+        H.merkle4_root(H.gen_b(1, "cuda"), tag, 1)
 
 
 def test_generators_and_digest(torch_cuda, H, oracle):

@@ -387,9 +387,11 @@ def test_merkle_argument_errors(torch_cuda, H, hades_lib):
     torch = torch_cuda
     t = torch.zeros((48, 4), dtype=torch.int64, device="cuda")
     with pytest.raises(ValueError):
-        H.merkle_root(t, 4, 1)                 # 48 is not a power of 4
+        H.merkle_root(t[:1], 4, 1)             # a tree needs at least two leaves
     with pytest.raises(ValueError):
-        H.merkle_root(t[:9], 3, 1)             # arity 3 unsupported
+        H.merkle_root(t[:25], 5, 1)            # arity 5 does not fit WIDTH = 5 (tag + children)
+    with pytest.raises(ValueError):
+        H.merkle_root(t[:9], 1, 1)             # arity 1 never shrinks: levels only
     tag = (ctypes.c_uint64 * 4)(1, 0, 0, 0)
     root = torch.zeros(4, dtype=torch.int64, device="cuda")
     # one-level tree: no scratch needed, NULL accepted

@@ -185,3 +185,146 @@ def test_multi_workers_concurrent_with_host_calls(torch_cuda, H, oracle):
     for t in threads:
         t.join()
     assert all(results.values()) and len(results) == len(threads), results
+
+
+# ---------------------------------------------------------------------------------------------
+# lane-split kernel: dispatch thresholds (1 024: one state per wave; 16 384: five waves per state; above: per lane)
+# ---------------------------------------------------------------------------------------------
+def test_default_dispatch_across_both_thresholds(torch_cuda, H, oracle):
+    torch = torch_cuda
+    for n in (1, 3, 4, 5, 1023, 1024, 1025, 2048, (1 << 14), (1 << 14) + 1):
+        inp = oracle.gen_b(11 * n, 5 * n)
+        guard = np.full(40, 0xDEADBEEFCAFEF00D, dtype=np.uint64)
+        exp = oracle.perm_batch(inp)
+        for kernel in (0, 4):
+            if kernel == 4 and n > 2048:
+                continue
+            buf = to_dev(torch, np.concatenate([guard, inp, guard]))
+            H.ScalarStrategy(kernel).perm(buf[40:40 + 20 * n])
+            got = to_host(buf)
+            assert (got[:40] == guard).all() and (got[-40:] == guard).all(), "wrote outside the batch"
+            assert (got[40:-40] == exp).all(), (n, kernel)
+
+
+def test_lanes_kernel_2pow18_vs_fast(torch_cuda, H):
+    torch = torch_cuda
+    a = H.gen_b(5 << 18, "cuda")
+    b = a.clone()
+    H.ScalarStrategy(2).perm(a)
+    H.ScalarStrategy(4).perm(b)
+    assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# general Merkle trees: arity 1..4, any number of leaves (padding table), openings, verification, forests
+# ---------------------------------------------------------------------------------------------
+TAG = {1: S.to_mont(1), 2: S.to_mont(3), 3: S.to_mont(7), 4: S.to_mont(15)}
+
+
+def rows(a):
+    return np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+
+
+@pytest.mark.parametrize("arity", [1, 2, 3, 4])
+def test_merkle_single_levels_all_arities_and_kernels(torch_cuda, H, oracle, arity):
+    """Full and ragged levels around every dispatch boundary (one parent per wave / five waves / per lane)."""
+    torch = torch_cuda
+    pad = oracle.gen_b(555, 1)
+    dpad = to_dev(torch, pad).view(1, 4)
+    for n_children in (1, arity, arity + 1, 5 * arity - 1, 64 * arity, 1024 * arity, 1024 * arity + 1, 1025 * arity - 1,
+                       5000 * arity, (1 << 14) * arity + 3, 40000 * arity - 2):
+        ch = oracle.gen_b(17 * n_children, n_children)
+        exp = oracle.merkle_level_pad(ch, arity, TAG[arity], 1, pad)
+        got = to_host(H.merkle_level(to_dev(torch, ch).view(-1, 4), arity, TAG[arity], 1, pad=dpad))
+        assert (got == exp).all(), (arity, n_children)
+    # zero padding when no table is given; out_idx other than 1
+    ch = oracle.gen_b(3, 7 * arity + (1 if arity > 1 else 0))
+    assert (to_host(H.merkle_level(to_dev(torch, ch).view(-1, 4), arity, TAG[arity], 3)) ==
+            oracle.merkle_level_pad(ch, arity, TAG[arity], 3)).all()
+
+
+@pytest.mark.parametrize("arity,n_leaves", [(3, 3 ** 9), (4, 4 ** 7 * 3), (2, 2), (2, 3), (3, 4), (4, 5), (2, 1000),
+                                            (3, 2 ** 15 + 11), (4, 100001), (4, 4 ** 8 + 1), (2, 2 ** 16 - 1)])
+def test_merkle_any_leaf_count_build_open_verify(torch_cuda, H, oracle, arity, n_leaves):
+    """Trees over arbitrary leaf counts with the empty-subtree padding table: every level vs the oracle, root-only path,
+    openings (incl. positions past the end of a level) and batched verification back to the root."""
+    torch = torch_cuda
+    tag = TAG[arity]
+    depth = H.merkle_depth(n_leaves, arity)
+    e0 = S.to_mont(0x5EED)
+    pad = H.merkle_empty_digests(arity, depth, e0, tag, 1)
+    opad = oracle.merkle_empty_digests(arity, depth, e0, tag, 1)
+    assert (to_host(pad).reshape(-1, 4) == opad).all()
+    leaves = oracle.gen_b(n_leaves, n_leaves)
+    dl = to_dev(torch, leaves).view(-1, 4)
+    levels = oracle.merkle_tree(leaves, arity, tag, 1, opad)
+    assert [l.size // 4 for l in levels] == H.merkle_level_sizes(n_leaves, arity) and len(levels) == depth
+    tree = H.merkle_build(dl, arity, tag, 1, pad=pad)
+    assert (to_host(tree) == np.concatenate(levels)).all()
+    assert (to_host(H.merkle_root(dl, arity, tag, 1, pad=pad)) == levels[-1]).all()
+    # zero padding (no table) is a different, equally well-defined tree
+    zl = oracle.merkle_tree(leaves, arity, tag, 1)
+    assert (to_host(H.merkle_root(dl, arity, tag, 1)) == zl[-1]).all()
+    # openings: first, last (its siblings are padding wherever the level is ragged), random
+    rng = random.Random(n_leaves)
+    idx = sorted(set([0, n_leaves - 1, n_leaves // 2] + [rng.randrange(n_leaves) for _ in range(61)]))
+    didx = torch.tensor(idx, dtype=torch.int64, device="cuda")
+    paths = H.merkle_open(dl, tree, arity, didx, pad=pad)
+    hp = to_host(paths).reshape(len(idx), depth, arity - 1, 4)
+    for q, i in enumerate(idx[:8] + idx[-8:]):
+        qq = idx.index(i)
+        assert (oracle.merkle_verify_path(rows(leaves)[i], i, hp[qq], arity, tag, 1) == levels[-1]).all(), i
+    roots = H.merkle_verify(dl[didx].contiguous(), didx, paths, arity, tag, 1)
+    assert bool((roots == to_dev(torch, levels[-1]).view(1, 4)).all())
+    # a tampered sibling or leaf no longer verifies
+    bad = paths.clone()
+    t = min(3, len(idx) - 1)
+    bad[t, depth - 1, 0, 0] ^= 1
+    r2 = H.merkle_verify(dl[didx].contiguous(), didx, bad, arity, tag, 1)
+    assert not bool((r2[t] == roots[t]).all()) and bool((r2[:t] == roots[:t]).all())
+
+
+def test_merkle_verify_2pow16_queries(torch_cuda, H, oracle):
+    torch = torch_cuda
+    n, arity, tag = 4 ** 8, 4, TAG[4]
+    leaves = H.gen_b(n, "cuda")
+    tree = H.merkle_build(leaves, arity, tag, 1)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(5)
+    idx = torch.randint(0, n, (1 << 16,), generator=g, dtype=torch.int64).cuda()
+    paths = H.merkle_open(leaves, tree, arity, idx)
+    roots = H.merkle_verify(leaves[idx].contiguous(), idx, paths, arity, tag, 1)
+    assert bool((roots == tree[-1:]).all())
+    # root of the same tree by the oracle (2^16 leaves = 21 845 permutations)
+    exp = oracle.merkle_tree(to_host(leaves), arity, tag, 1)[-1]
+    assert (to_host(tree[-1]) == exp).all()
+    # arity 1 chains: verify = depth successive single-child hashes
+    chain = oracle.gen_b(9, 300)
+    d1 = to_dev(torch, chain).view(-1, 4)
+    r1 = H.merkle_verify(d1, torch.zeros(300, dtype=torch.int64, device="cuda"),
+                         torch.zeros((300, 5, 0, 4), dtype=torch.int64, device="cuda"), 1, TAG[1], 1)
+    cur = chain
+    for _ in range(5):
+        cur = oracle.merkle_level(cur, 1, TAG[1], 1)
+    assert (to_host(r1) == cur).all()
+
+
+@pytest.mark.parametrize("arity,k,n_trees", [(4, 4, 10 ** 4), (4, 1, 1000), (2, 10, 333), (3, 5, 2000), (4, 6, 7)])
+def test_merkle_forest_vs_oracle(torch_cuda, H, oracle, arity, k, n_trees):
+    torch = torch_cuda
+    per = arity ** k
+    leaves = H.gen_b(n_trees * per, "cuda")
+    roots = to_host(H.merkle_forest(leaves, n_trees, arity, TAG[arity], 1)).reshape(n_trees, 4)
+    host = to_host(leaves)
+    # the forest's levels are one big level each: oracle level by level over all trees at once
+    cur = host
+    for _ in range(k):
+        cur = oracle.merkle_level(cur, arity, TAG[arity], 1)
+    assert (roots.reshape(-1) == cur).all()
+    # and a single tree of the forest equals merkle_root of its leaves
+    t = n_trees // 2
+    if per >= 2:
+        one = to_host(H.merkle_root(leaves[t * per:(t + 1) * per], arity, TAG[arity], 1))
+        assert (one == roots[t]).all()
+    with pytest.raises(Exception):
+        H.merkle_forest(leaves[: n_trees * per - 1], n_trees, arity, TAG[arity], 1)

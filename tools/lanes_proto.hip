@@ -1,0 +1,213 @@
+// lanes_proto.hip -- the lane-split Montgomery product (hades_lanes.cuh) against the per-lane one (mont_fips):
+// (1) same field element on random and edge operands, (2) time of a dependent chain in ONE wave.
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Ihades252_amd/csrc -o build_tools/lanes_proto tools/lanes_proto.hip
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <chrono>
+#include <vector>
+#include "hades_constants.inc"
+#include "hades_fast.cuh"
+#include "hades_lanes.cuh"
+using namespace hades;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ const uint32_t d_p29[kNL] = HADES_P29;
+__device__ const uint32_t d_pinv29[kNL] = HADES_NEG_PINV29;
+__device__ const int32_t d_unit[16] = HADES_RP_MOD_P29;          // mont(x, Rp mod p) = x
+
+__device__ __forceinline__ LaneConsts load_consts() {
+    LaneConsts K;
+#pragma unroll
+    for (int i = 0; i < kNL; i++) {
+        K.p[i] = d_p29[i];
+        K.pinv[i] = d_pinv29[i];
+    }
+    return K;
+}
+
+// pairs: [n][2][9] lazy limbs.  Row r of the grid handles pair r: out_lane[r] = finalize(mont(lane product, unit)),
+// out_ref[r] = finalize(mont(mont_mul(a, b), unit)).  mode 1: S-box instead of the product (b ignored).
+__global__ void k_check(const int32_t *pairs, uint32_t *out_lane, uint32_t *out_ref, int n, int mode) {
+    __shared__ int32_t xch[16][16];                                // [row of the block][lane]
+    const LaneConsts K = load_consts();
+    const int row = threadIdx.x >> 4, k = threadIdx.x & 15;
+    const int pair = blockIdx.x * (blockDim.x / 16) + row;
+    const bool live = pair < n;
+    uint32_t a = 0, b = 0;
+    if (live && k < kNL) {
+        a = pairs[(pair * 2 + 0) * kNL + k];
+        b = pairs[(pair * 2 + 1) * kNL + k];
+    }
+    const uint32_t r = mode == 1 ? lane_sbox(K, a) : lane_mont_mul(K, a, b);
+    xch[row][k] = r;
+    __syncthreads();
+    if (live && k == 0) {
+        F29 fa, fb, fr;
+        for (int i = 0; i < kNL; i++) {
+            fa.l[i] = pairs[(pair * 2 + 0) * kNL + i];
+            fb.l[i] = pairs[(pair * 2 + 1) * kNL + i];
+            fr.l[i] = xch[row][i];
+        }
+        Fr x = finalize(mont_mul_const(fr, d_unit));
+        Fr y = finalize(mont_mul_const(mode == 1 ? sbox29(fa) : mont_mul(fa, fb), d_unit));
+        for (int i = 0; i < 8; i++) {
+            out_lane[pair * 8 + i] = x.l[i];
+            out_ref[pair * 8 + i] = y.l[i];
+        }
+        // lanes 9..15 of the result must be zero
+        int bad = 0;
+        for (int i = kNL; i < 16; i++) bad |= xch[row][i];
+        if (bad) out_lane[pair * 8] ^= 0xdeadbeef;
+    }
+}
+
+// one wave: `iters` dependent S-boxes, lane-split (mode 0) or per-lane (mode 1)
+__global__ void k_chain(const int32_t *seed, int32_t *out, int iters, int mode, unsigned long long *stamps) {
+    const LaneConsts K = load_consts();
+    const int k = threadIdx.x & 15;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if (mode == 0) {
+        uint32_t x = k < kNL ? (uint32_t)seed[k] : 0u;
+        for (int i = 0; i < iters; i++) {
+            x = lane_sbox(K, x);
+            asm volatile("" : "+v"(x));
+        }
+        out[threadIdx.x] = x;
+    } else {
+        F29 x;
+        for (int i = 0; i < kNL; i++) x.l[i] = seed[i];
+        for (int i = 0; i < iters; i++) {
+            x = sbox29(x);
+            for (int j = 0; j < kNL; j++) limb_fence(x.l[j]);
+        }
+        for (int j = 0; j < kNL; j++) out[threadIdx.x * kNL + j] = x.l[j];
+    }
+    if (threadIdx.x == 0) {
+        stamps[0] = __builtin_amdgcn_s_memtime() - c0;          // shader clock cycles
+        stamps[1] = __builtin_amdgcn_s_memrealtime() - r0;      // 100 MHz ticks
+    }
+}
+
+// the whole permutation of one state by one wave, stamped: entry, after the input stage, after the 67 rounds, exit
+__device__ const LanesTables d_lanes = {HADES_LANES_ROUND_INIT, HADES_COOP_FINAL_F, HADES_FAST_MDS_SMALL, HADES_P29,
+                                        HADES_P29, HADES_NEG_PINV29};
+__global__ void k_perm_stamped(uint8_t *state, unsigned long long *stamps) {
+    __shared__ LanesLds L;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const int lane = threadIdx.x & 63;
+    Fr in;
+    for (int i = 0; i < 8; i++) in.l[i] = 0;
+    if (lane < 5) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(state + lane * 32);
+        const uint4 lo = q[0], hi = q[1];
+        in.l[0] = lo.x; in.l[1] = lo.y; in.l[2] = lo.z; in.l[3] = lo.w;
+        in.l[4] = hi.x; in.l[5] = hi.y; in.l[6] = hi.z; in.l[7] = hi.w;
+    }
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+    const Fr out = lanes_perm(&d_lanes, L, in, st);
+    if (lane < 5) {
+        uint4 *q = reinterpret_cast<uint4 *>(state + lane * 32);
+        q[0] = make_uint4(out.l[0], out.l[1], out.l[2], out.l[3]);
+        q[1] = make_uint4(out.l[4], out.l[5], out.l[6], out.l[7]);
+    }
+    if (threadIdx.x == 0) {
+        stamps[0] = st[0] - t0;
+        stamps[1] = st[1] - st[0];
+        stamps[2] = __builtin_amdgcn_s_memtime() - st[1];
+        for (int i = 2; i < 6; i++) stamps[1 + i] = st[i];
+    }
+}
+
+static uint64_t rng_state = 0x1234567887654321ull;
+static uint64_t rnd() {
+    rng_state ^= rng_state << 13;
+    rng_state ^= rng_state >> 7;
+    rng_state ^= rng_state << 17;
+    return rng_state;
+}
+
+int main() {
+    const int n = 4096;
+    std::vector<int32_t> pairs(n * 2 * kNL);
+    for (int i = 0; i < n; i++)
+        for (int o = 0; o < 2; o++)
+            for (int k = 0; k < kNL; k++) {
+                int32_t v;
+                const int kind = i % 8;                                                          // unsigned limbs <= 2^30 + 1
+                if (kind == 0) v = (int32_t)(rnd() & kMask29);                                  // normalised
+                else if (kind == 1) v = (int32_t)(rnd() % ((1u << 30) + 2));                     // lazy
+                else if (kind == 2) v = (1 << 30) + 1;                                           // maximal
+                else if (kind == 3) v = (rnd() & 1) ? (1 << 30) + 1 : 0;
+                else if (kind == 4) v = (rnd() & 1) ? (1 << 29) + 2 : (int32_t)kMask29;
+                else if (kind == 5) v = k == 0 ? (int32_t)(rnd() & 3) : 0;                       // tiny values
+                else if (kind == 6) v = (int32_t)kMask29;                                        // all ones
+                else v = (int32_t)(rnd() & kMask29) * ((rnd() & 7) == 0 ? 0 : 1);                // sparse
+                if (k == kNL - 1 && v >= (1 << 25)) v = (int32_t)(rnd() & ((1 << 25) - 1));      // value < 2^257
+                pairs[(i * 2 + o) * kNL + k] = v;
+            }
+    int32_t *d_pairs;
+    uint32_t *d_a, *d_b;
+    CK(hipMalloc(&d_pairs, pairs.size() * 4));
+    CK(hipMalloc(&d_a, n * 32));
+    CK(hipMalloc(&d_b, n * 32));
+    CK(hipMemcpy(d_pairs, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
+    std::vector<uint32_t> ha(n * 8), hb(n * 8);
+    for (int mode = 0; mode < 2; mode++) {
+        hipLaunchKernelGGL(k_check, dim3((n + 15) / 16), dim3(256), 0, 0, d_pairs, d_a, d_b, n, mode);   // (the per-lane reference
+        // of the S-box overflows its signed columns on limbs of 2^30: kinds 2, 3 may differ there -- see the Python model)
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(ha.data(), d_a, n * 32, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hb.data(), d_b, n * 32, hipMemcpyDeviceToHost));
+        int bad = 0, first = -1;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < 8; j++)
+                if (ha[i * 8 + j] != hb[i * 8 + j]) {
+                    bad++;
+                    if (first < 0) first = i;
+                    break;
+                }
+        printf("%s: %d pairs, %d mismatches%s\n", mode ? "lane S-box vs sbox29" : "lane product vs mont_fips", n, bad,
+               bad ? "  <-- FAIL" : "  (bit-identical after full reduction)");
+        if (bad) printf("  first mismatch: pair %d (kind %d)\n", first, first % 8);
+    }
+    // timing: one wave, dependent chain
+    int32_t *d_seed, *d_out;
+    unsigned long long *d_st, h_st[2];
+    CK(hipMalloc(&d_st, 16));
+    CK(hipMalloc(&d_seed, 64));
+    CK(hipMalloc(&d_out, 64 * kNL * 4));
+    CK(hipMemcpy(d_seed, pairs.data(), kNL * 4, hipMemcpyHostToDevice));
+    for (int mode = 0; mode < 2; mode++) {
+        for (int iters : {2000, 20000}) {
+            hipLaunchKernelGGL(k_chain, dim3(1), dim3(64), 0, 0, d_seed, d_out, iters, mode, d_st);
+            CK(hipDeviceSynchronize());
+            auto t0 = std::chrono::steady_clock::now();
+            hipLaunchKernelGGL(k_chain, dim3(1), dim3(64), 0, 0, d_seed, d_out, iters, mode, d_st);
+            CK(hipDeviceSynchronize());
+            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            CK(hipMemcpy(h_st, d_st, 16, hipMemcpyDeviceToHost));
+            printf("%s: %d dependent S-boxes in one wave: %.3f ms = %.1f ns per S-box (%.1f ns per product); in-kernel: %llu "
+                   "cycles = %.1f per S-box, clock %.3f GHz\n",
+                   mode ? "per-lane (sbox29)  " : "lane-split (4 rows)", iters, dt * 1e3, dt / iters * 1e9, dt / iters / 3 * 1e9,
+                   h_st[0], (double)h_st[0] / iters, (double)h_st[0] / (double)h_st[1] * 0.1);
+        }
+    }
+    // the whole permutation, stamped
+    uint8_t *d_state;
+    unsigned long long *d_st3, h3[7];
+    CK(hipMalloc(&d_state, 160));
+    CK(hipMalloc(&d_st3, 56));
+    CK(hipMemset(d_state, 1, 160));
+    for (int rep = 0; rep < 3; rep++) {
+        hipLaunchKernelGGL(k_perm_stamped, dim3(1), dim3(64), 0, 0, d_state, d_st3);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(h3, d_st3, 56, hipMemcpyDeviceToHost));
+        printf("one permutation by one wave (stamped): input stage %llu cycles, 67 rounds %llu cycles (%.1f per round), output stage %llu cycles\n",
+               h3[0], h3[1], h3[1] / 67.0, h3[2]);
+        printf("   partial rounds: products + exchange %.1f, linear layer %.1f cycles per round;  full rounds: %.1f, %.1f\n",
+               h3[3] / 59.0, h3[4] / 59.0, h3[5] / 8.0, h3[6] / 8.0);
+    }
+    return 0;
+}

@@ -23,12 +23,13 @@ cap = (1 << 64) * RM % P
 
 def sec_device():
     print("== device-resident kernels")
-    for logn in (0, 6, 10, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26):
+    for logn in (0, 2, 6, 8, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26):
         n = 1 << logn
         buf = H.gen_b(5 * n, dev)
-        for k, name in ((2, "fast"), (3, "coop"), (1, "literal")):
+        for k, name in ((2, "fast"), (3, "coop"), (4, "lanes"), (1, "literal")):
             if k == 1 and logn > 24: continue
             if k == 3 and logn > 22: continue
+            if k == 4 and logn > 18: continue
             s = H.ScalarStrategy(k)
             dt = timed(lambda: s.perm(buf), reps=3 if logn > 20 else 20)
             print("n=2^%-2d %-8s %9.3f ms  %8.2f Mperm/s  %7.2f GB/s algorithmic" % (logn, name, dt * 1e3, n / dt / 1e6, 320 * n / dt / 1e9))
@@ -158,19 +159,23 @@ def sec_host():
 
 
 def sec_latency():
-    print("== small-call latency, host-pointer path (pooled stream + buffer)")
-    for n in (1, 64, 4096, 16384):
+    print("== small-call latency: host-pointer call (hades252_perm_batch, default dispatch) and device call + sync per kernel")
+    for n in (1, 4, 64, 256, 1024, 2048, 4096, 16384):
         host = H.gen_b(5 * n, dev).cpu().numpy().view(np.uint64).reshape(-1).copy()
-        for k, name in ((0, "default"), (2, "fast")):
-            s = H.ScalarStrategy(k)
-            if k == 2:
-                # host path always uses the default dispatch; time the device-resident call + sync instead
-                buf = H.gen_b(5 * n, dev)
-                dt = timed(lambda: (s.perm(buf), torch.cuda.synchronize()), reps=50)
-                print("n=%-5d device call + sync, per-lane kernel %8.1f us" % (n, dt * 1e6))
-            else:
-                dt = timed(lambda: s.perm(host), reps=50)
-                print("n=%-5d host call (H2D + kernel + D2H)      %8.1f us" % (n, dt * 1e6))
+        s = H.ScalarStrategy(0)
+        ts = []
+        for _ in range(7):
+            ts.append(timed(lambda: s.perm(host), reps=50))
+        print("n=%-5d host call (in + kernel + out), default dispatch: median %8.1f us  min %8.1f us" % (n, sorted(ts)[3] * 1e6, min(ts) * 1e6))
+        buf = H.gen_b(5 * n, dev)
+        for k, name in ((4, "lanes (one state per wave)"), (3, "coop (five waves per state)"), (2, "fast (one state per lane)")):
+            sk = H.ScalarStrategy(k)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev = []
+            for _ in range(30):
+                a.record(); sk.perm(buf); b.record(); torch.cuda.synchronize(); ev.append(a.elapsed_time(b) * 1e3)
+            dt = timed(lambda: (sk.perm(buf), torch.cuda.synchronize()), reps=50)
+            print("n=%-5d %-30s kernel (HIP events) median %8.1f us  min %8.1f us;  call + sync %8.1f us" % (n, name, sorted(ev)[15], min(ev), dt * 1e6))
 
 
 def sec_wire():
