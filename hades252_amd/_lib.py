@@ -88,6 +88,12 @@ SIGNATURES = {
     "hades252_sponge_hash_dev": (c_int, [c_void_p, c_size_t, c_size_t, POINTER(c_uint64), c_int, c_void_p, c_void_p]),
     "hades252_sponge_hash_var_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, POINTER(c_uint64), c_int,
                                              c_void_p, c_void_p, c_void_p]),
+    "hades252_sponge_sort_scratch_bytes": (c_size_t, [c_size_t]),
+    "hades252_sponge_hash_var_ex_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, POINTER(c_uint64), c_int,
+                                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hades252_sponge_init_dev": (c_int, [c_void_p, c_size_t, POINTER(c_uint64), c_void_p]),
+    "hades252_sponge_absorb_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "hades252_sponge_squeeze_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "hades252_gen_b_dev": (c_int, [c_void_p, c_uint64, c_size_t, c_uint64, c_void_p]),
     "hades252_gen_a_dev": (c_int, [c_void_p, c_uint64, c_size_t, c_void_p]),
     "hades252_digest_dev": (c_int, [c_void_p, c_uint64, c_size_t, c_void_p, c_void_p]),

@@ -669,14 +669,17 @@ __global__ void __launch_bounds__(kBlock, 3) k_sponge(const uint8_t *__restrict_
                                                       const uint64_t *__restrict__ offsets,
                                                       const uint64_t *__restrict__ lengths,
                                                       uint8_t *__restrict__ digests, size_t n_msgs, size_t fixed_len,
-                                                      Fr capacity, int pad_mode, size_t n_scalars, int *bad_count) {
+                                                      Fr capacity, int pad_mode, size_t n_scalars, int *bad_count,
+                                                      const uint32_t *__restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *slab = wave_slab<4>(lds);
     constexpr int kRec = lds_rec_bytes(4);
     const int lane = threadIdx.x & (kWave - 1);
     const size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
-    const size_t me = rec0 + lane;
-    const bool live = me < n_msgs;
+    const bool live = rec0 + lane < n_msgs;
+    // `order` (may be NULL): the messages sorted by block count (k_sponge_* below), so that the 64 messages of a wave
+    // need about the same number of permutations; slot rec0 + lane then hashes message order[rec0 + lane]
+    const size_t me = !live ? 0 : (order != nullptr ? (size_t)order[rec0 + lane] : rec0 + lane);
     const uint64_t off = live ? (offsets != nullptr ? offsets[me] : (uint64_t)me * fixed_len) : 0;
     uint64_t len = live ? (lengths != nullptr ? lengths[me] : (uint64_t)fixed_len) : 0;
     // a message that does not lie inside the pool is never read: it is hashed as the empty message and counted
@@ -740,8 +743,110 @@ __global__ void __launch_bounds__(kBlock, 3) k_sponge(const uint8_t *__restrict_
         for (int w = 0; w < 5; w++) st[w] = out[w];
         if (t + 1 == blocks) dig = st[1];
     }
+    if (order != nullptr) {                    // scattered: every lane stores its own 32 bytes
+        if (live) store_word(digests + me * 32, dig);
+        return;
+    }
     slab_put<1>(slab, 0, dig);
     slab_flush<1>(digests, rec0, n_msgs, slab);
+}
+
+// ---- ragged batches: counting sort of the message indices by block count --------------------------------
+// Three small launches over scratch = {counters[kSpongeBuckets + 1] (u32), order[n_msgs] (u32)}:
+//   count: histogram of min(blocks, kSpongeBuckets - 1);  scan: exclusive prefix sums (one block);  scatter: every
+//   message takes the next free slot of its bucket.  The order inside a bucket depends on atomics and is irrelevant:
+//   every digest goes to its own message's slot.
+constexpr int kSpongeBuckets = 1024;
+__device__ __forceinline__ uint32_t sponge_bucket(const uint64_t *lengths, size_t i, int pad_mode) {
+    uint64_t b = (lengths[i] + (pad_mode == 1 ? 1 : 0) + 3) / 4;
+    if (b == 0) b = 1;
+    return (uint32_t)(b < (uint64_t)kSpongeBuckets ? b : (uint64_t)kSpongeBuckets - 1);
+}
+__global__ void __launch_bounds__(kBlock) k_sponge_count(const uint64_t *__restrict__ lengths, size_t n_msgs, int pad_mode,
+                                                         uint32_t *__restrict__ counters) {
+    __shared__ uint32_t hist[kSpongeBuckets];
+    for (int i = threadIdx.x; i < kSpongeBuckets; i += kBlock) hist[i] = 0;
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_msgs; i += stride)
+        atomicAdd(&hist[sponge_bucket(lengths, i, pad_mode)], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSpongeBuckets; i += kBlock)
+        if (hist[i]) atomicAdd(&counters[i], hist[i]);
+}
+// counters[b] <- number of messages in buckets LONGER than b (long messages first: the tail of the grid is short work)
+__global__ void __launch_bounds__(kSpongeBuckets) k_sponge_scan(uint32_t *__restrict__ counters) {
+    __shared__ uint32_t v[kSpongeBuckets];
+    const int b = threadIdx.x;
+    v[b] = counters[kSpongeBuckets - 1 - b];          // reversed: slot b holds bucket (last - b)
+    __syncthreads();
+    for (int d = 1; d < kSpongeBuckets; d <<= 1) {    // inclusive Hillis-Steele scan
+        const uint32_t add = b >= d ? v[b - d] : 0;
+        __syncthreads();
+        v[b] += add;
+        __syncthreads();
+    }
+    counters[kSpongeBuckets - 1 - b] = b ? v[b - 1] : 0;
+}
+// One tile of kBlock messages per block: ranks inside the tile come from LDS atomics, and a block reserves its slots of
+// every bucket it meets with ONE global atomic (2 M messages with ~10 distinct block counts would otherwise queue on ~10
+// addresses).
+__global__ void __launch_bounds__(kBlock) k_sponge_scatter(const uint64_t *__restrict__ lengths, size_t n_msgs, int pad_mode,
+                                                           uint32_t *__restrict__ counters, uint32_t *__restrict__ order) {
+    __shared__ uint32_t hist[kSpongeBuckets];          // count of the tile, then the tile's base slot, per bucket
+    for (int i = threadIdx.x; i < kSpongeBuckets; i += kBlock) hist[i] = 0;
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    uint32_t b = 0, rank = 0;
+    if (i < n_msgs) {
+        b = sponge_bucket(lengths, i, pad_mode);
+        rank = atomicAdd(&hist[b], 1u);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < kSpongeBuckets; j += kBlock)
+        if (hist[j]) hist[j] = atomicAdd(&counters[j], hist[j]);
+    __syncthreads();
+    if (i < n_msgs) order[hist[b] + rank] = (uint32_t)i;
+}
+
+// ---- streaming sponge: the state lives in device memory between calls -------------------------------------
+// absorb: for each of `blocks_each` blocks of 4 scalars, words 1..4 of every state += block, then the permutation
+// (what one round of dusk-poseidon's sponge does, README.md:9); blocks[i][t][0..3] is block t of state i.
+__global__ void __launch_bounds__(kBlock, 3) k_sponge_absorb(uint8_t *states, const uint8_t *__restrict__ blocks,
+                                                             size_t n, int blocks_each) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<5>(lds);
+    const size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    const size_t me = rec0 + (threadIdx.x & (kWave - 1));
+    Fr st[5];
+    wave_load_records<5>(states, rec0, n, slab, st);
+#pragma unroll 1
+    for (int t = 0; t < blocks_each; t++) {
+        if (me < n) {
+            const uint8_t *b = blocks + (me * (size_t)blocks_each + t) * 128;
+#pragma unroll
+            for (int k = 0; k < 4; k++) st[1 + k] = fr_add(st[1 + k], load_word(b + k * 32));
+        }
+        Fr out[5];
+        fast_perm<5>(&d_fast, st, out, 0);
+#pragma unroll
+        for (int w = 0; w < 5; w++) st[w] = out[w];
+    }
+    wave_store_records<5>(states, rec0, n, slab, st);
+}
+// states[i] = [capacity, 0, 0, 0, 0]
+__global__ void __launch_bounds__(kBlock) k_sponge_init(uint8_t *states, size_t n, Fr capacity) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;      // one 32-byte word per thread
+    if (i >= n * 5) return;
+    store_word(states + i * 32, i % 5 == 0 ? capacity : zero_word());
+}
+// digests[i] = word `idx` of state i
+__global__ void __launch_bounds__(kBlock) k_sponge_squeeze(const uint8_t *__restrict__ states, uint8_t *__restrict__ digests,
+                                                           size_t n, int idx) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;      // one 16-byte half word per thread
+    if (i >= n * 2) return;
+    *reinterpret_cast<uint4 *>(digests + i * 16) =
+        *reinterpret_cast<const uint4 *>(states + (i >> 1) * 160 + (size_t)idx * 32 + (i & 1) * 16);
 }
 
 __device__ __forceinline__ uint64_t splitmix_limb(uint64_t seed, uint64_t idx) {
@@ -1570,15 +1675,10 @@ int hades252_merkle4_level_dev(const void *d_children, void *d_parents, size_t n
 
 static int sponge_launch(const void *d_scalars, const uint64_t *d_offsets, const uint64_t *d_lengths, size_t n_msgs,
                          size_t fixed_len, const uint64_t capacity_mont[4], int pad_mode, void *d_digests, void *stream,
-                         size_t n_scalars, int *d_bad_count) {
-    Fr cap;
-    for (int k = 0; k < 4; k++) {
-        cap.l[2 * k] = (uint32_t)capacity_mont[k];
-        cap.l[2 * k + 1] = (uint32_t)(capacity_mont[k] >> 32);
-    }
+                         size_t n_scalars, int *d_bad_count, const uint32_t *d_order) {
     hipLaunchKernelGGL(k_sponge, dim3(blocks_for(n_msgs)), dim3(kBlock), lds_for(4), (hipStream_t)stream,
-                       (const uint8_t *)d_scalars, d_offsets, d_lengths, (uint8_t *)d_digests, n_msgs, fixed_len, cap,
-                       pad_mode, n_scalars, d_bad_count);
+                       (const uint8_t *)d_scalars, d_offsets, d_lengths, (uint8_t *)d_digests, n_msgs, fixed_len,
+                       fr_from_u64(capacity_mont), pad_mode, n_scalars, d_bad_count, d_order);
     HIP_TRY(hipGetLastError());
     return HADES252_OK;
 }
@@ -1590,19 +1690,83 @@ int hades252_sponge_hash_dev(const void *d_msgs, size_t n_msgs, size_t msg_len, 
         (pad_mode != 0 && pad_mode != 1) || n_msgs > kMaxLaunchRecords || misaligned(d_msgs) || misaligned(d_digests))
         return HADES252_ERR_INVALID_ARG;
     return sponge_launch(d_msgs, nullptr, nullptr, n_msgs, msg_len, capacity_mont, pad_mode, d_digests, stream,
-                         n_msgs * msg_len, nullptr);
+                         n_msgs * msg_len, nullptr, nullptr);
 }
 
-int hades252_sponge_hash_var_dev(const void *d_scalars, size_t n_scalars, const uint64_t *d_offsets,
-                                 const uint64_t *d_lengths, size_t n_msgs, const uint64_t capacity_mont[4], int pad_mode,
-                                 void *d_digests, int *d_bad_count, void *stream) {
+size_t hades252_sponge_sort_scratch_bytes(size_t n_msgs) {
+    return ((size_t)kSpongeBuckets + n_msgs) * 4 + 16;
+}
+
+// d_scratch != NULL (hades252_sponge_sort_scratch_bytes(n_msgs) bytes): the messages are first sorted by block count on
+// the device, so that a wave's 64 lanes hash messages of (nearly) the same length -- ragged batches then keep > 90 % of
+// the lanes doing useful permutations instead of ~50 %.  Same digests either way.
+int hades252_sponge_hash_var_ex_dev(const void *d_scalars, size_t n_scalars, const uint64_t *d_offsets,
+                                    const uint64_t *d_lengths, size_t n_msgs, const uint64_t capacity_mont[4], int pad_mode,
+                                    void *d_digests, int *d_bad_count, void *d_scratch, size_t scratch_bytes, void *stream) {
     if (n_msgs == 0) return HADES252_OK;
     if (d_digests == nullptr || capacity_mont == nullptr || d_offsets == nullptr || d_lengths == nullptr ||
         (d_scalars == nullptr && n_scalars > 0) || (pad_mode != 0 && pad_mode != 1) || n_msgs > kMaxLaunchRecords ||
         misaligned(d_scalars) || misaligned(d_digests))
         return HADES252_ERR_INVALID_ARG;
+    const uint32_t *order = nullptr;
+    if (d_scratch != nullptr) {
+        if (scratch_bytes < hades252_sponge_sort_scratch_bytes(n_msgs)) return HADES252_ERR_SCRATCH;
+        if (misaligned(d_scratch)) return HADES252_ERR_INVALID_ARG;
+        hipStream_t s = (hipStream_t)stream;
+        uint32_t *counters = (uint32_t *)d_scratch, *ord = counters + kSpongeBuckets + 4;
+        HIP_TRY(hipMemsetAsync(counters, 0, (size_t)kSpongeBuckets * 4, s));
+        const unsigned grid = (unsigned)(blocks_for(n_msgs) < 2048 ? blocks_for(n_msgs) : 2048);
+        hipLaunchKernelGGL(k_sponge_count, dim3(grid), dim3(kBlock), 0, s, d_lengths, n_msgs, pad_mode, counters);
+        hipLaunchKernelGGL(k_sponge_scan, dim3(1), dim3(kSpongeBuckets), 0, s, counters);
+        hipLaunchKernelGGL(k_sponge_scatter, dim3(blocks_for(n_msgs)), dim3(kBlock), 0, s, d_lengths, n_msgs, pad_mode,
+                           counters, ord);
+        HIP_TRY(hipGetLastError());
+        order = ord;
+    }
     return sponge_launch(d_scalars, d_offsets, d_lengths, n_msgs, 0, capacity_mont, pad_mode, d_digests, stream,
-                         n_scalars, d_bad_count);
+                         n_scalars, d_bad_count, order);
+}
+
+int hades252_sponge_hash_var_dev(const void *d_scalars, size_t n_scalars, const uint64_t *d_offsets,
+                                 const uint64_t *d_lengths, size_t n_msgs, const uint64_t capacity_mont[4], int pad_mode,
+                                 void *d_digests, int *d_bad_count, void *stream) {
+    return hades252_sponge_hash_var_ex_dev(d_scalars, n_scalars, d_offsets, d_lengths, n_msgs, capacity_mont, pad_mode,
+                                           d_digests, d_bad_count, nullptr, 0, stream);
+}
+
+// ---- streaming sponge ---------------------------------------------------------------------------
+int hades252_sponge_init_dev(void *d_states, size_t n_states, const uint64_t capacity_mont[4], void *stream) {
+    if (n_states == 0) return HADES252_OK;
+    if (d_states == nullptr || capacity_mont == nullptr || n_states > kMaxLaunchRecords / 5 || misaligned(d_states))
+        return HADES252_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_sponge_init, dim3(blocks_for(n_states * 5)), dim3(kBlock), 0, (hipStream_t)stream,
+                       (uint8_t *)d_states, n_states, fr_from_u64(capacity_mont));
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
+int hades252_sponge_absorb_dev(void *d_states, const void *d_blocks, size_t n_states, int blocks_each, void *stream) {
+    if (blocks_each < 0) return HADES252_ERR_INVALID_ARG;
+    if (n_states == 0 || blocks_each == 0) return HADES252_OK;
+    if (d_states == nullptr || d_blocks == nullptr || n_states > kMaxLaunchRecords || misaligned(d_states) ||
+        misaligned(d_blocks))
+        return HADES252_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_sponge_absorb, dim3(blocks_for(n_states)), dim3(kBlock), lds_for(5), (hipStream_t)stream,
+                       (uint8_t *)d_states, (const uint8_t *)d_blocks, n_states, blocks_each);
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
+int hades252_sponge_squeeze_dev(const void *d_states, void *d_digests, size_t n_states, int word, void *stream) {
+    if (word < 0 || word >= 5) return HADES252_ERR_INVALID_ARG;
+    if (n_states == 0) return HADES252_OK;
+    if (d_states == nullptr || d_digests == nullptr || n_states > kMaxLaunchRecords / 2 || misaligned(d_states) ||
+        misaligned(d_digests))
+        return HADES252_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_sponge_squeeze, dim3(blocks_for(n_states * 2)), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const uint8_t *)d_states, (uint8_t *)d_digests, n_states, word);
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
 }
 
 size_t hades252_merkle_tree_bytes(size_t n_leaves, int arity) {

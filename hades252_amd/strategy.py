@@ -497,9 +497,11 @@ def sponge_hash(msgs_t, msg_len: int, capacity_mont: int, pad_mode: int = 1):
     return out
 
 
-def sponge_hash_var(scalars_t, offsets_t, lengths_t, capacity_mont: int, pad_mode: int = 1):
+def sponge_hash_var(scalars_t, offsets_t, lengths_t, capacity_mont: int, pad_mode: int = 1, sort: bool = False):
     """Batched variable-length sponge: message i = scalars[offsets[i] : offsets[i] + lengths[i]]
-    (offsets / lengths: int64 CUDA tensors, in scalars).  Returns [n, 4] int64 digests."""
+    (offsets / lengths: int64 CUDA tensors, in scalars).  Returns [n, 4] int64 digests.  ``sort``: order the messages
+    by block count on the device first (ragged batches: the 64 messages of a wave then need the same number of
+    permutations); same digests."""
     import torch
     sptr, n_scalars, dev = _dev_buffer(scalars_t, 32, "sponge_hash_var")
     optr, n, _ = _dev_buffer(offsets_t, 8, "sponge_hash_var")
@@ -508,12 +510,55 @@ def sponge_hash_var(scalars_t, offsets_t, lengths_t, capacity_mont: int, pad_mod
         raise ValueError("sponge_hash_var: offsets and lengths differ in size")
     out = torch.empty((n, 4), dtype=torch.int64, device=dev)
     bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    scratch, sbytes = None, 0
+    if sort:
+        sbytes = _lib.lib().hades252_sponge_sort_scratch_bytes(n)
+        scratch = torch.empty((sbytes + 15) // 16 * 2, dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
-        check(_lib.lib().hades252_sponge_hash_var_dev(sptr, n_scalars, optr, lptr, n, _tag_arr(capacity_mont), pad_mode,
-                                                      out.data_ptr(), bad.data_ptr(), _stream_ptr(dev)), "sponge_hash_var")
+        check(_lib.lib().hades252_sponge_hash_var_ex_dev(sptr, n_scalars, optr, lptr, n, _tag_arr(capacity_mont), pad_mode,
+                                                         out.data_ptr(), bad.data_ptr(),
+                                                         scratch.data_ptr() if sort else 0, sbytes, _stream_ptr(dev)),
+              "sponge_hash_var")
     if int(bad.item()) != 0:
         raise IndexError("sponge_hash_var: %d message(s) reach outside the scalar pool" % int(bad.item()))
     return out
+
+
+# Named, NOT pinned parameter sets (dusk-poseidon is outside the reference tree, README.md:9): include/hades252.h
+SPONGE_PRESETS = {"sponge/pad10": {"capacity": 1 << 64, "pad_mode": 1, "digest_word": 1},
+                  "merkle/arity4": {"tag": 15, "arity": 4, "digest_word": 1}}
+
+
+class SpongeStates:
+    """Streaming sponge (``hades252_sponge_init_dev`` / ``_absorb_dev`` / ``_squeeze_dev``): n states resident on the
+    device; absorb blocks of 4 scalars whenever they arrive, squeeze when done."""
+
+    def __init__(self, n: int, capacity_mont: int, device="cuda"):
+        import torch
+        self.states = torch.empty((n, WIDTH, 4), dtype=torch.int64, device=device)
+        with torch.cuda.device(self.states.device):
+            check(_lib.lib().hades252_sponge_init_dev(self.states.data_ptr(), n, _tag_arr(capacity_mont),
+                                                      _stream_ptr(self.states.device)), "sponge_init")
+
+    def absorb(self, blocks_t) -> None:
+        """blocks_t: [n, blocks_each, 4 scalars] (any shape with n * blocks_each * 128 bytes, state-major)."""
+        import torch
+        n = self.states.shape[0]
+        ptr, n_blocks, dev = _dev_buffer(blocks_t, 128, "sponge_absorb")
+        if n == 0 or n_blocks % n:
+            raise ValueError("sponge_absorb: %d blocks do not split evenly over %d states" % (n_blocks, n))
+        with torch.cuda.device(dev):
+            check(_lib.lib().hades252_sponge_absorb_dev(self.states.data_ptr(), ptr, n, n_blocks // n, _stream_ptr(dev)),
+                  "sponge_absorb")
+
+    def squeeze(self, word: int = 1):
+        import torch
+        n, dev = self.states.shape[0], self.states.device
+        out = torch.empty((n, 4), dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            check(_lib.lib().hades252_sponge_squeeze_dev(self.states.data_ptr(), out.data_ptr(), n, word, _stream_ptr(dev)),
+                  "sponge_squeeze")
+        return out
 
 
 GEN_SEED = 0x4861646573323532

@@ -244,10 +244,32 @@ int hades252_sponge_hash_dev(const void *d_msgs, size_t n_msgs, size_t msg_len, 
  * lengths in scalars, device arrays of n_msgs u64; messages may overlap or leave gaps; length 0 allowed).
  * n_scalars = size of the pool: a message that does not lie inside it is never read -- it is hashed as the empty
  * message and d_bad_count (device int, may be NULL) is incremented.
- * Same absorption / padding rule per message as above (CONVENTION UNPINNED: parameters, see above). */
+ * Same absorption / padding rule per message as above (CONVENTION UNPINNED: parameters, see above).
+ * Every lane of a wave runs to the longest message among the wave's 64.  _ex with d_scratch != NULL
+ * (hades252_sponge_sort_scratch_bytes(n_msgs) bytes of device memory) first sorts the message indices by block count
+ * on the device (three small launches), so that a wave's messages are alike: ragged batches keep > 90 % of the lanes
+ * on useful permutations instead of ~50 %.  The digests are the same and land in message order either way. */
 int hades252_sponge_hash_var_dev(const void *d_scalars, size_t n_scalars, const uint64_t *d_offsets,
                                  const uint64_t *d_lengths, size_t n_msgs, const uint64_t capacity_mont[4], int pad_mode,
                                  void *d_digests, int *d_bad_count, void *stream);
+size_t hades252_sponge_sort_scratch_bytes(size_t n_msgs);
+int hades252_sponge_hash_var_ex_dev(const void *d_scalars, size_t n_scalars, const uint64_t *d_offsets,
+                                    const uint64_t *d_lengths, size_t n_msgs, const uint64_t capacity_mont[4], int pad_mode,
+                                    void *d_digests, int *d_bad_count, void *d_scratch, size_t scratch_bytes, void *stream);
+/* Streaming sponge: the states (160 B each, the AoS format of the perm entry points) live in device memory between
+ * calls, so a caller can keep absorbing.  init: state = [capacity, 0, 0, 0, 0]; absorb: for t < blocks_each, words
+ * 1..4 += d_blocks[i][t][0..3] (4 scalars = 128 B per block, state-major), then the permutation; squeeze: d_digests[i]
+ * = word `word` of state i (dusk-poseidon's sponge returns word 1).  Padding is the caller's: the final block carries
+ * whatever padding scalars the convention wants.  init + absorb of ceil(len / 4) zero-filled blocks + squeeze(1)
+ * equals hades252_sponge_hash_dev with pad_mode 0. */
+int hades252_sponge_init_dev(void *d_states, size_t n_states, const uint64_t capacity_mont[4], void *stream);
+int hades252_sponge_absorb_dev(void *d_states, const void *d_blocks, size_t n_states, int blocks_each, void *stream);
+int hades252_sponge_squeeze_dev(const void *d_states, void *d_digests, size_t n_states, int word, void *stream);
+/* Named parameter sets a dusk-poseidon caller would pass -- NAMED, NOT PINNED: that crate is outside the reference
+ * tree (README.md:9 only names it); the values below are the commonly described conventions, to be checked against
+ * the crate version in use:
+ *   "sponge/pad10"   capacity = 2^64 (Montgomery form), pad_mode 1 (a single 1, then zeros), digest = word 1
+ *   "merkle/arity4"  tag = 2^4 - 1 = 15 in word 0, children in words 1..4, digest = word 1 */
 
 /* ---- synthetic inputs and digests (benchmark / verification plumbing) --------------------- */
 /* Generator B: scalar e (global element index first_elem + k) gets 4 splitmix64 limbs, top limb

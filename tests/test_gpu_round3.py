@@ -328,3 +328,82 @@ def test_merkle_forest_vs_oracle(torch_cuda, H, oracle, arity, k, n_trees):
         assert (one == roots[t]).all()
     with pytest.raises(Exception):
         H.merkle_forest(leaves[: n_trees * per - 1], n_trees, arity, TAG[arity], 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# sponge: device-side sort of ragged batches, streaming absorb / squeeze
+# ---------------------------------------------------------------------------------------------
+CAP = S.to_mont(1 << 64)
+
+
+@pytest.mark.parametrize("pad", [0, 1])
+def test_sponge_sorted_equals_unsorted_and_oracle(torch_cuda, H, oracle, pad):
+    """Ragged lengths (0 .. 70 scalars, a few very long, one beyond the last sort bucket): the device-sorted run gives
+    the same digests in message order as the plain run and the oracle."""
+    torch = torch_cuda
+    rng = random.Random(77 + pad)
+    n = 5000
+    lens = [rng.choice([0, 1, 3, 4, 5, 8, 9, 17, 33, 70]) if rng.random() < 0.8 else rng.randrange(0, 40) for _ in range(n)]
+    lens[123] = 4 * 1030                                     # > 1023 blocks: clamps into the last bucket
+    lens[4000] = 600
+    offs = np.cumsum([0] + lens[:-1]).astype(np.uint64)
+    pool = oracle.gen_b(8, int(sum(lens)) + 1)
+    lens_a = np.array(lens, dtype=np.uint64)
+    exp = oracle.sponge_var(pool, offs, lens_a, CAP, pad)
+    dp, do, dl = to_dev(torch, pool).view(-1, 4), to_dev(torch, offs), to_dev(torch, lens_a)
+    plain = to_host(H.sponge_hash_var(dp, do, dl, CAP, pad))
+    srt = to_host(H.sponge_hash_var(dp, do, dl, CAP, pad, sort=True))
+    assert (plain == exp).all() and (srt == exp).all()
+    # tiny batches and n not a multiple of the block size
+    for m in (1, 2, 63, 65, 257):
+        e = oracle.sponge_var(pool, offs[:m], lens_a[:m], CAP, pad)
+        assert (to_host(H.sponge_hash_var(dp, do[:m].contiguous(), dl[:m].contiguous(), CAP, pad, sort=True)) == e).all()
+
+
+def test_sponge_sort_argument_errors(torch_cuda, hades_lib, H):
+    torch = torch_cuda
+    pool = H.gen_b(64, "cuda")
+    off = torch.zeros(8, dtype=torch.int64, device="cuda")
+    ln = torch.full((8,), 4, dtype=torch.int64, device="cuda")
+    out = torch.zeros((8, 4), dtype=torch.int64, device="cuda")
+    cap = (ctypes.c_uint64 * 4)(1, 0, 0, 0)
+    small = torch.zeros(8, dtype=torch.int64, device="cuda")
+    need = hades_lib.hades252_sponge_sort_scratch_bytes(8)
+    assert need >= (1024 + 8) * 4
+    assert hades_lib.hades252_sponge_hash_var_ex_dev(pool.data_ptr(), 64, off.data_ptr(), ln.data_ptr(), 8, cap, 1,
+                                                     out.data_ptr(), None, small.data_ptr(), 64, None) == -5
+    assert hades_lib.hades252_sponge_hash_var_ex_dev(pool.data_ptr(), 64, off.data_ptr(), ln.data_ptr(), 8, cap, 1,
+                                                     out.data_ptr(), None, small.data_ptr() + 8, need, None) == -1
+
+
+def test_streaming_sponge_absorb_squeeze(torch_cuda, H, oracle):
+    """init + absorb (in one call, in two calls, block by block) + squeeze == the one-shot sponge without padding, and
+    the full state after each absorb == the oracle's add-then-permute."""
+    torch = torch_cuda
+    n, t = 3000, 5
+    msgs = oracle.gen_b(21, n * t * 4)                       # n messages of 4 t scalars
+    exp = oracle.sponge(msgs, 4 * t, CAP, 0)
+    dm = to_dev(torch, msgs).view(n, t, 4, 4)
+    a = H.SpongeStates(n, CAP)
+    a.absorb(dm)
+    assert (to_host(a.squeeze()) == exp).all()
+    b = H.SpongeStates(n, CAP)
+    b.absorb(dm[:, :2].contiguous())
+    b.absorb(dm[:, 2:].contiguous())
+    assert torch.equal(a.states, b.states)
+    c = H.SpongeStates(n, CAP)
+    for i in range(t):
+        c.absorb(dm[:, i].contiguous())
+    assert torch.equal(a.states, c.states)
+    # the whole state, not only the digest word: one absorb of one block vs oracle arithmetic
+    d = H.SpongeStates(7, CAP)
+    blk = oracle.gen_b(99, 7 * 4)
+    d.absorb(to_dev(torch, blk).view(7, 1, 4, 4))
+    st = np.zeros((7, 5, 4), dtype=np.uint64)
+    st[:, 0] = np.array(limbs_of(CAP), dtype=np.uint64)
+    st[:, 1:] = blk.reshape(7, 4, 4)                          # 0 + block
+    assert (to_host(d.states) == oracle.perm_batch(st.reshape(-1))).all()
+    for w in range(5):
+        assert (to_host(d.squeeze(w)).reshape(7, 4) == to_host(d.states).reshape(7, 5, 4)[:, w]).all()
+    # the C ABI equivalence promised in the header: pad_mode 0 one-shot == streaming
+    assert (to_host(H.sponge_hash(to_dev(torch, msgs).view(-1, 4), 4 * t, CAP, 0)) == exp).all()

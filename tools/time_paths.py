@@ -69,7 +69,29 @@ def sec_merkle():
     idx = torch.randint(0, n, (1 << 16,), dtype=torch.int64, device=dev)
     dto = timed(lambda: H.merkle_open(leaves, tree, 4, idx), reps=5)
     print("build (all levels kept) leaves=2^24 %9.3f ms;  2^16 openings (12 levels x 3 siblings) %8.3f ms" % (dt * 1e3, dto * 1e3))
-    del tree, leaves
+    pths = H.merkle_open(leaves, tree, 4, idx)
+    lv = leaves[idx].contiguous()
+    roots = H.merkle_verify(lv, idx, pths, 4, tag, 1)
+    dtv = timed(lambda: H.merkle_verify(lv, idx, pths, 4, tag, 1), reps=5)
+    print("verify 2^16 openings of the 2^24-leaf tree (12 permutations each): %8.3f ms  %8.2f Mperm/s  all roots ok: %s"
+          % (dtv * 1e3, 12 * (1 << 16) / dtv / 1e6, bool((roots == tree[-1:]).all())))
+    del tree, leaves, pths, lv
+    for nt, k in ((4096, 4), (10 ** 4, 4), (1 << 16, 2)):
+        per = 4 ** k
+        fl = H.gen_b(nt * per, dev)
+        sc = torch.empty(max(_lib.lib().hades252_merkle_forest_scratch_bytes(nt, per, 4) // 8, 2), dtype=torch.int64, device=dev)
+        dt = timed(lambda: H.merkle_forest(fl, nt, 4, tag, 1, sc), reps=10)
+        nodes = nt * (per - 1) // 3
+        print("forest of %d arity-4 trees of 4^%d leaves: %8.3f ms  %d perms  %8.2f Mperm/s" % (nt, k, dt * 1e3, nodes, nodes / dt / 1e6))
+        del fl
+    for n_any, ar in ((3 ** 9, 3), (4 ** 7 * 3, 4), (10 ** 6, 4), (10 ** 6 + 1, 2)):
+        lf = H.gen_b(n_any, dev)
+        tg = (2 ** ar - 1) * RM % P
+        pad = H.merkle_empty_digests(ar, H.merkle_depth(n_any, ar), 0, tg, 1)
+        dt = timed(lambda: H.merkle_root(lf, ar, tg, 1, pad=pad), reps=5)
+        nodes = sum(H.merkle_level_sizes(n_any, ar))
+        print("arity %d, %d leaves (padding table of empty subtrees): %8.3f ms  %d perms  %8.2f Mperm/s" % (ar, n_any, dt * 1e3, nodes, nodes / dt / 1e6))
+        del lf
     for logn in (16, 20):
         n = 1 << logn
         leaves = H.gen_b(n, dev)
@@ -238,10 +260,17 @@ def sec_sponge_var():
     offs = torch.cumsum(lens, 0) - lens
     pool = H.gen_b(int(lens.sum().item()) + 1, dev)
     dl, do = lens.to(dev), offs.to(dev)
-    dt = timed(lambda: H.sponge_hash_var(pool, do, dl, cap, 1), reps=3)
     perms = int(((lens + 1 + 3) // 4).sum().item())
-    wave_max = int(((lens + 1 + 3) // 4).view(-1, 256).max(dim=1).values.sum().item()) * 256
-    print("n=2^21 ragged %8.3f ms  %8.2f Mhash/s  %8.2f M useful perm/s  (%.2f M lane-perm/s incl. masked lanes)" % (dt * 1e3, nmsg / dt / 1e6, perms / dt / 1e6, wave_max / dt / 1e6))
+    wave_max = int(((lens + 1 + 3) // 4).view(-1, 64).max(dim=1).values.sum().item()) * 64
+    for srt in (False, True):
+        dt = timed(lambda: H.sponge_hash_var(pool, do, dl, cap, 1, sort=srt), reps=5)
+        print("n=2^21 ragged, %-28s %8.3f ms  %8.2f Mhash/s  %8.2f M useful perm/s%s"
+              % ("sorted by block count first" if srt else "message order", dt * 1e3, nmsg / dt / 1e6, perms / dt / 1e6,
+                 "" if srt else "  (%.2f M lane-perm/s issued incl. idle lanes: %.0f %% useful)" % (wave_max / dt / 1e6, 100.0 * perms / wave_max)))
+    st = H.SpongeStates(1 << 22, cap)
+    blk = H.gen_b((1 << 22) * 4, dev).view(1 << 22, 1, 4, 4)
+    dt = timed(lambda: st.absorb(blk), reps=5)
+    print("streaming absorb, 2^22 states x 1 block: %8.3f ms  %8.2f Mperm/s" % (dt * 1e3, (1 << 22) / dt / 1e6))
 
 
 if __name__ == "__main__":
