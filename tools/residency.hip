@@ -99,6 +99,28 @@ __global__ void k_fill(uint64_t *p, size_t n) {
         p[i] = z;
     }
 }
+// A/B for the north-star wording "constants broadcast from LDS": the same kernel, but every block first copies the
+// 17 KB of round records to LDS and the rounds read them from there (wave-uniform addresses: ds_read broadcasts into
+// VGPRs) instead of from the scalar cache into SGPRs.
+template <int BLOCK, int MINW>
+__global__ void __launch_bounds__(BLOCK, MINW) k_perm_ldsc(uint8_t *states, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ FastTables Ts;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(&d_fast);
+        uint4 *dst = reinterpret_cast<uint4 *>(&Ts);
+        for (int i = threadIdx.x; i < (int)(sizeof(FastTables) / 16); i += BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    size_t rec0 = (size_t)blockIdx.x * BLOCK + (threadIdx.x / kWave) * kWave;
+    uint8_t *slab = lds + (threadIdx.x / kWave) * lds_wave_bytes(5);
+    Fr st[5];
+    wave_load_records<5>(states, rec0, n, slab, st);
+    Fr out[5];
+    fast_perm<5>(&Ts, st, out, 0);
+    wave_store_records<5>(states, rec0, n, slab, out);
+}
+
 __global__ void k_xor(const uint64_t *p, size_t n, unsigned long long *out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t v = 0;
@@ -123,7 +145,7 @@ static void sweep(const char *name, kern_t k, int block, size_t lds_need, size_t
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     unsigned grid = (unsigned)((n + block - 1) / block);
     uint64_t sum = 0;
-    for (int rep = 0; rep < 6; rep++) {
+    for (int rep = 0; rep < 8; rep++) {
         hipLaunchKernelGGL(k_fill, dim3((unsigned)((n * 20 + 255) / 256)), dim3(256), 0, 0, (uint64_t *)d, n * 20);
         CHECK(hipEventRecord(e0));
         hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds, 0, d, n);
@@ -166,5 +188,12 @@ int main() {
     sweep("256thr lb4 half-slab pad->4/CU", k_perm<256, 4, 1>, 256, 4 * half, 40 * 1024 - 4 * half, d, n, d_sum);
     sweep("256thr lb4 half-slab pad->3/CU", k_perm<256, 4, 1>, 256, 4 * half, 50 * 1024 - 4 * half, d, n, d_sum);
     sweep("128thr lb5 half-slab", k_perm<128, 5, 1>, 128, 2 * half, 0, d, n, d_sum);
+    // round records from LDS instead of SGPRs (median of 7); its 17 KB leave room for 2 blocks per CU, so the SGPR kernel
+    // at 2 blocks per CU ("pad->2/CU" above, repeated here) is the like-for-like partner
+    printf("-- constants: scalar loads into SGPRs (shipped) vs a per-block LDS copy read by ds_read broadcasts\n");
+    sweep("SGPR constants, 3 blocks/CU (shipped)", k_perm<256, 4, 0>, 256, 4 * full, 0, d, n, d_sum);
+    sweep("SGPR constants, padded to 2 blocks/CU", k_perm<256, 4, 0>, 256, 4 * full, 70 * 1024 - 4 * full, d, n, d_sum);
+    sweep("LDS constants (2 blocks/CU)", k_perm_ldsc<256, 4>, 256, 4 * full, 0, d, n, d_sum);
+    sweep("LDS constants, launch bounds 2", k_perm_ldsc<256, 2>, 256, 4 * full, 0, d, n, d_sum);
     return 0;
 }
