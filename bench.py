@@ -26,7 +26,8 @@ Also in the line:
                 built in this image) timed on this host (rank 0) on a bounded sample of the same
                 workload; the same sample is used to check the GPU output bit for bit.
   secondary     outside `value`: BASELINE.json configs[3] (arity-4 Merkle tree over 2^24 leaves: tree
-                time, nodes/s, its own roofline with 160 B per node), and `host_path`: the entry point a
+                time, nodes/s, its own roofline with 160 B per node), `single_perm` (ONE permutation: device
+                and host-call latency), and `host_path`: the entry point a
                 Rust `Strategy::perm` binds (`hades252_perm_batch`: host memory in, host memory out,
                 PCIe-inclusive) on 2^22 states against this box's measured bidirectional copy ceiling.
 `--workload merkle` times the tree build itself as the step (development; the driver runs the default).
@@ -216,6 +217,38 @@ def merkle_record(H, torch, device, log_leaves: int, reps: int = 5):
                          "algorithmic_bytes_per_node": MERKLE_BYTES_PER_NODE}}, leaves
 
 
+def single_perm_record(H, torch, device):
+    """The reference's own call shape: ONE permutation (README.md:60-61).  Device-side: HIP events around
+    hades252_perm_batch_dev on one resident state (default dispatch = the lane-split kernel; the events include the launch
+    gap of a few microseconds -- profiles/r3/ holds the rocprofv3 kernel durations); host call: hades252_perm_batch on 20
+    limbs of ordinary memory, wall clock.  The CPU port's time for one permutation on one thread stands beside them."""
+    import numpy as np
+    strat = H.ScalarStrategy()
+    buf = H.gen_b(5, device)
+    host = buf.cpu().numpy().view(np.uint64).reshape(-1).copy()
+    for _ in range(20):
+        strat.perm(buf)
+    torch.cuda.synchronize()
+    ev = []
+    for _ in range(101):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        strat.perm(buf)
+        b.record()
+        torch.cuda.synchronize()
+        ev.append(a.elapsed_time(b) * 1e3)
+    for _ in range(20):
+        strat.perm(host)
+    ts = []
+    for _ in range(101):
+        t0 = time.perf_counter()
+        strat.perm(host)
+        ts.append((time.perf_counter() - t0) * 1e6)
+    return {"workload": "one WIDTH=5 permutation (BASELINE configs[0] shape), default dispatch: k_perm_lanes",
+            "device_us_median": sorted(ev)[50], "device_us_min": min(ev),
+            "host_call_us_median": sorted(ts)[50], "host_call_us_min": min(ts)}
+
+
 def host_path_record(log_n: int = 22):
     """The boundary a Rust `Strategy::perm` binds: `hades252_perm_batch` on host memory (PCIe-inclusive; never
     `value`), measured by a NATIVE caller -- tools/host_path_bench.cpp, a plain C++ program linked against the
@@ -383,6 +416,7 @@ def main():
             sec["merkle_2p24"], leaves = merkle_record(H, torch, device, 24)
             del leaves
             torch.cuda.empty_cache()
+            sec["single_perm"] = single_perm_record(H, torch, device)
             sec["host_path"] = host_path_record(22)
         except Exception as e:                       # secondary records never take the headline down
             sec["error"] = repr(e)

@@ -121,5 +121,25 @@ public:
     }
 };
 
+// A batch of states in page-locked host memory (hades252_host_alloc): `perm` on it goes straight to DMA instead of
+// page-locking the slice inside every call.  Movable, frees on destruction.
+class PinnedStates {
+    BlsScalar *p_ = nullptr;
+    std::size_t len_ = 0;
+
+public:
+    explicit PinnedStates(std::size_t n_states) : len_(n_states * WIDTH) {
+        void *raw = nullptr;
+        check(hades252_host_alloc(&raw, (len_ ? len_ : 1) * sizeof(BlsScalar)), "host_alloc");
+        p_ = static_cast<BlsScalar *>(raw);
+    }
+    PinnedStates(const PinnedStates &) = delete;
+    PinnedStates &operator=(const PinnedStates &) = delete;
+    PinnedStates(PinnedStates &&o) noexcept : p_(o.p_), len_(o.len_) { o.p_ = nullptr; o.len_ = 0; }
+    ~PinnedStates() { if (p_) (void)hades252_host_free(p_); }
+    BlsScalar *data() { return p_; }
+    std::size_t len() const { return len_; }          // scalars: WIDTH per state
+};
+
 }  // namespace dusk_hades
 #endif

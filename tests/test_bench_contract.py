@@ -34,6 +34,8 @@ def test_bench_single_and_two_ranks_agree():
     mk, hp = one["secondary"]["merkle_2p24"], one["secondary"]["host_path"]
     assert mk["nodes"] == 5592405 and 0 < mk["tree_ms"] < 100 and mk["roofline"]["algorithmic_bytes_per_node"] == 160
     assert hp["bit_exact_vs_device_path"] is True and 0 < hp["frac_of_ceiling"] < 1.2 and hp["perms"] == 1 << 22
+    sp = one["secondary"]["single_perm"]
+    assert 20 < sp["device_us_median"] < 150 and sp["device_us_min"] <= sp["host_call_us_median"] < 400
     assert one["config"]["kernel"] == "k_perm_fast" and "valu_issue" in one and "frac_of_measured" not in one["valu_issue"]
     assert one["n_gpus"] == 1 and one["parity_vs_cpu_sample"] is True
     assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1

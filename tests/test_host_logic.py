@@ -68,3 +68,12 @@ def test_merkle_subtree_split():
     for bad in ((1 << 23, 2), (1 << 24, 3), (4, 4)):
         with pytest.raises(ValueError):
             merkle.subtree_split(*bad)
+
+
+def test_merkle_shape_helpers():
+    """n_l = ceil(n_{l-1} / arity): the level sizes the builder, the openings and the oracle wrapper all use."""
+    assert H.merkle_level_sizes(16, 4) == [4, 1] and H.merkle_level_sizes(8, 2) == [4, 2, 1]
+    assert H.merkle_level_sizes(12, 4) == [3, 1] and H.merkle_level_sizes(16, 3) == [6, 2, 1]
+    assert H.merkle_level_sizes(2, 4) == [1] and H.merkle_level_sizes(5, 2) == [3, 2, 1]
+    assert sum(H.merkle_level_sizes(4 ** 7, 4)) == (4 ** 7 - 1) // 3
+    assert set(H.SPONGE_PRESETS) == {"sponge/pad10", "merkle/arity4"}

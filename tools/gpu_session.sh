@@ -3,13 +3,15 @@
 # (kernel trace + separate PMC passes on bench.py, wire-format kernels and the VALU-ceiling microbenchmark).
 #   gpurun --timeout 3600 -- 'bash tools/gpu_session.sh r2'
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.txt 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/pytest_gpu_$TAG.txt
 tail -4 gpurun_out/pytest_gpu_$TAG.txt
 timeout 600 ./build_tools/ubench3 > gpurun_out/ubench3_$TAG.txt 2>&1; echo "ubench3 rc=$?"
+timeout 120 ./build_tools/lanes_proto > gpurun_out/lanes_proto_$TAG.txt 2>&1; echo "lanes_proto rc=$?"
+timeout 120 ./build_tools/pcie_probe 640 > gpurun_out/pcie_probe_$TAG.txt 2>&1; echo "pcie_probe rc=$?"
 timeout 300 ./build_tools/residency > gpurun_out/residency_$TAG.txt 2>&1; echo "residency rc=$?"
 timeout 120 ./build_tools/dfma_proto > gpurun_out/dfma_proto_$TAG.txt 2>&1; echo "dfma rc=$?"
 timeout 900 python tools/time_paths.py > gpurun_out/time_paths_$TAG.txt 2>&1; echo "time_paths rc=$?"

@@ -8,12 +8,15 @@ OUT=$REPO/gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-secondary"
 cd $REPO
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py $ARGS > $OUT/bench_write.json 2> $OUT/pmc_write.log
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_sq -- python3 bench.py $ARGS > $OUT/bench_sq.json 2> $OUT/pmc_sq.log
+# the latency kernels on one state + the 2^16-leaf tree (kernel durations only)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_latency -- python3 tools/lat_one.py > /dev/null 2> $OUT/trace_latency.log
+find $OUT/trace_latency -name "*kernel_stats.csv" | head -1 | xargs cat > $OUT/latency_kernel_stats.csv
 python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # wire-format kernels beyond the Infinity Cache, with HBM byte counters
