@@ -279,7 +279,8 @@ __device__ __forceinline__ uint32_t lane_mds_row(const uint32_t (&c)[5], const u
 //                  barrier), every row computes the output row(s) of its own word(s): two passes of lane_mds_row
 // Constants come from global memory by per-lane loads one round ahead (a round is ~1500 cycles: cold misses hide).
 struct LanesTables {
-    uint32_t round[67][64];     // per round {A[5][9] plain limbs, G[9], zeros}
+    uint32_t round[68][64];     // per round {A[5][9] plain limbs, G[9], zeros}; row 67 is all zero (fetched ahead by the
+                                // last round, never used)
     int32_t final_f[kNL + 7];   // mont(X, final_f) = x * 2^256 (per-lane arithmetic of the last step)
     uint32_t mds[5][8];         // small-integer MDS rows
     uint32_t p16[16];           // limb k of p in lane k, zero for k >= 9
@@ -327,7 +328,10 @@ __device__ __forceinline__ Fr lanes_perm(const LanesTables *T, LanesLds &L, cons
     }
     lanes_fence();
     uint32_t A = L.io[word_a][k], B = L.io[3][k];
-    uint32_t c_a = T->round[0][off_a], c_b = T->round[0][off_b], c_g = T->round[0][off_g];
+    // round r's three constants of this lane sit at rec[off_*]; rec advances by one 256-byte record per round (a scalar
+    // pointer: the per-lane part of the address never changes)
+    const uint32_t *rec = &T->round[0][0];
+    uint32_t c_a = rec[off_a], c_b = rec[off_b], c_g = rec[off_g];
     if (stamps != nullptr) {
         asm volatile("" : "+v"(A), "+v"(B), "+v"(c_a), "+v"(c_b), "+v"(c_g));
         stamps[0] = __builtin_amdgcn_s_memtime();
@@ -335,8 +339,8 @@ __device__ __forceinline__ Fr lanes_perm(const LanesTables *T, LanesLds &L, cons
 #pragma unroll 1
     for (int r = 0; r < 67; r++) {
         const bool full = r < 4 || r >= 63;
-        const int rn = r + 1 < 67 ? r + 1 : r;                       // next round's constants, fetched now
-        const uint32_t n_a = T->round[rn][off_a], n_b = T->round[rn][off_b], n_g = T->round[rn][off_g];
+        rec += 64;                                                   // next round's constants, fetched now
+        const uint32_t n_a = rec[off_a], n_b = rec[off_b], n_g = rec[off_g];
         unsigned long long ts0 = 0, ts1 = 0;
         if (stamps != nullptr) ts0 = __builtin_amdgcn_s_memtime();
         A += c_a;
