@@ -22,10 +22,10 @@ LIB = os.path.join(CSRC, "libhades252.so")
 STAMP = LIB + ".stamp"
 LOCK = LIB + ".lock"
 SOURCES = ["hades252.hip"]
-DEPS = ["hades252.hip", "fr32.cuh", "staging.cuh", "hades_literal.cuh", "hades_fast.cuh", "k_perm_fast.cuh", "hades_coop.cuh", "hades_lanes.cuh",
+DEPS = ["hades252.hip", "fr32.hpp", "staging.hpp", "hades_literal.hpp", "hades_fast.hpp", "k_perm_fast.hpp", "hades_coop.hpp", "hades_lanes.hpp",
         "hades_constants.inc", os.path.join("..", "..", "include", "hades252.h")]
 # what the dominant kernel (k_perm_fast) is made of: profiles recorded for it stay valid while these are unchanged
-PERM_FAST_DEPS = ["fr32.cuh", "staging.cuh", "hades_fast.cuh", "k_perm_fast.cuh"]
+PERM_FAST_DEPS = ["fr32.hpp", "staging.hpp", "hades_fast.hpp", "k_perm_fast.hpp"]
 # ... plus these tables of hades_constants.inc (other kernels' tables may change without touching k_perm_fast)
 PERM_FAST_TABLES = ("HADES_FAST_L", "HADES_FAST_MDS_SMALL", "HADES_NEG_P29", "HADES_TWO_P29", "HADES_FAST_ROUND_INIT",
                     "HADES_FAST_FINAL_F")

@@ -1,4 +1,4 @@
-// fr32.cuh -- BLS12-381 scalar field Fr on gfx950, saturated 8 x u32 limbs, Montgomery R = 2^256.
+// fr32.hpp -- BLS12-381 scalar field Fr on gfx950, saturated 8 x u32 limbs, Montgomery R = 2^256.
 //
 // This is the memory-format arithmetic: values are exactly the reference's in-memory
 // `BlsScalar` (4 x u64 LE limbs of value*R mod p, fully reduced), viewed as 8 x u32.

@@ -10,14 +10,14 @@
 #include <vector>
 
 #include "../../include/hades252.h"
-#include "fr32.cuh"
+#include "fr32.hpp"
 #include "hades_constants.inc"
-#include "hades_literal.cuh"
-#include "staging.cuh"
-#include "hades_fast.cuh"
-#include "k_perm_fast.cuh"
-#include "hades_coop.cuh"
-#include "hades_lanes.cuh"
+#include "hades_literal.hpp"
+#include "staging.hpp"
+#include "hades_fast.hpp"
+#include "k_perm_fast.hpp"
+#include "hades_coop.hpp"
+#include "hades_lanes.hpp"
 
 using namespace hades;
 
@@ -32,15 +32,15 @@ __device__ const uint32_t d_mds_mont[25][8] = HADES_MDS_MONT_INIT;
 __device__ const uint32_t d_r2[8] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu,
                                      0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
 
-// d_fast (the throughput kernel's round records) is defined next to its kernel in k_perm_fast.cuh
-// low-latency schedule (hades_coop.cuh)
+// d_fast (the throughput kernel's round records) is defined next to its kernel in k_perm_fast.hpp
+// low-latency schedule (hades_coop.hpp)
 __device__ const CoopTables d_coop = {HADES_COOP_ROUND_INIT, HADES_COOP_FINAL_F, HADES_FAST_MDS_SMALL};
-// lane-split schedule (hades_lanes.cuh): the coop schedule with plain-limb round constants + the reduction constants
+// lane-split schedule (hades_lanes.hpp): the coop schedule with plain-limb round constants + the reduction constants
 __device__ const LanesTables d_lanes = {HADES_LANES_ROUND_INIT, HADES_COOP_FINAL_F, HADES_FAST_MDS_SMALL, HADES_P29,
                                         HADES_P29, HADES_NEG_PINV29};
 // trace kernel: U_r with mont(X_after_round_r, U_r) = x * 2^256
 __device__ const int32_t d_trace_u[67][16] = HADES_FAST_TRACE_U_INIT;
-// ... + D_r: the partial-round constants of words 0..3 that the shipped schedule defers (hades_fast.cuh item 5)
+// ... + D_r: the partial-round constants of words 0..3 that the shipped schedule defers (hades_fast.hpp item 5)
 __device__ const uint32_t d_trace_d[67][5][8] = HADES_FAST_TRACE_D_INIT;
 // witness kernel: un-scaling factors {u_in,u2,u4,u5,w1,u_post} and additive corrections {d1[5], d2[5]} per round
 struct WitnessTables {
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_perm_witness(const uint8_t *__res
 
 // Generic batched BlsScalar operations (reference call sites src/strategies/scalar.rs:28,33,44;
 // src/round_constants.rs:41): out[i] = a[i] (op) b[i] on Montgomery limbs, fully reduced.
-// IMPL 0: the saturated 8 x u32 CIOS arithmetic of fr32.cuh (what the literal kernels use);
+// IMPL 0: the saturated 8 x u32 CIOS arithmetic of fr32.hpp (what the literal kernels use);
 // IMPL 1: the radix-2^29 signed-limb arithmetic of the shipped kernel (to_f29, mont_fips, finalize).
 // These exist so that tests can drive BOTH device arithmetics through the computations that produced
 // the reference's constant blobs (tests/test_gpu_blob_kat.py), and as a13's batched surface.
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_merkle_verify(const uint8_t *__re
     wave_store_records<1>(roots, rec0, n_queries, slab, node);
 }
 
-// ---- low-latency kernels: five waves per state (hades_coop.cuh) --------------------------------------
+// ---- low-latency kernels: five waves per state (hades_coop.hpp) --------------------------------------
 // In-place permutation of up to 64 states per 320-thread block.
 __global__ void __launch_bounds__(kCoopThreads) k_perm_coop(uint8_t *states, size_t n) {
     __shared__ CoopLds L;
@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(kCoopThreads) k_perm_coop(uint8_t *states, siz
     }
 }
 
-// ---- lowest-latency kernels: one state per WAVE, every field element spread over a 16-lane row (hades_lanes.cuh) ---
+// ---- lowest-latency kernels: one state per WAVE, every field element spread over a 16-lane row (hades_lanes.hpp) ---
 constexpr int kLanesWaves = 4;                   // states per block
 // In-place permutation, one state per wave (no block-wide barrier anywhere: idle waves simply leave).
 __global__ void __launch_bounds__(kLanesWaves *kWave) k_perm_lanes(uint8_t *states, size_t n) {
@@ -951,7 +951,7 @@ static Fr fr_from_u64(const uint64_t v[4]) {
 // of one per-lane wave (crossover measured on MI355X: profiles/r2/time_paths.txt)
 static constexpr size_t kCoopMaxStates = (size_t)1 << 14;
 // ... and one this small (at most one wave per SIMD) is fastest with one state per wave, every product spread over a
-// 16-lane row (hades_lanes.cuh): about half the latency of the five-waves kernel
+// 16-lane row (hades_lanes.hpp): about half the latency of the five-waves kernel
 static constexpr size_t kLanesMaxStates = (size_t)1 << 10;
 
 // one parent per lane (any size, any arity, ragged levels)
@@ -1059,7 +1059,7 @@ int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int
     if (d_states == nullptr || misaligned(d_states)) return HADES252_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     uint8_t *p = (uint8_t *)d_states;
-    // small batches are latency-bound: five waves per state (hades_coop.cuh); large ones one state per lane
+    // small batches are latency-bound: five waves per state (hades_coop.hpp); large ones one state per lane
     if (kernel == HADES252_KERNEL_DEFAULT)
         kernel = n_perms <= kLanesMaxStates ? HADES252_KERNEL_LANES
                                             : (n_perms <= kCoopMaxStates ? HADES252_KERNEL_COOP : HADES252_KERNEL_FAST);

@@ -1,4 +1,4 @@
-// hades_coop.cuh -- the low-latency schedule of the permutation: five waves per state.
+// hades_coop.hpp -- the low-latency schedule of the permutation: five waves per state.
 //
 // k_perm_fast keeps a whole state in one lane: ideal for throughput, but a permutation is then ~89 k
 // DEPENDENT VALU instructions of one wave -- 187 us however few states there are (measured: a lone wave
@@ -19,7 +19,7 @@
 // Constants: hades252_amd/_derive.py::coop_schedule (every round compounds the scale s -> s^5/Rp^4/(lam 2^29)).
 // tests/test_fast_model.py::coop_perm_model replays this kernel limb for limb with the word bounds asserted.
 #pragma once
-#include "hades_fast.cuh"
+#include "hades_fast.hpp"
 
 namespace hades {
 
@@ -48,7 +48,7 @@ struct CoopTables {
 struct CoopLds {
     __attribute__((aligned(16))) int32_t rc[67][64];            // 17 152 B: CoopTables::round
     int32_t xw[2][5][kNL][kWave];                               // 23 040 B
-    __attribute__((aligned(16))) uint8_t stage[kWave * 176];    // 64 records, padded like staging.cuh
+    __attribute__((aligned(16))) uint8_t stage[kWave * 176];    // 64 records, padded like staging.hpp
 };
 
 // first thing a cooperative kernel does (followed by a barrier before the first coop_rounds)
@@ -58,7 +58,7 @@ __device__ __forceinline__ void coop_load_constants(const CoopTables *T, CoopLds
     for (int i = threadIdx.x; i < 67 * 64 / 4; i += kCoopThreads) dst[i] = src[i];
 }
 
-// One output row of small_mds (hades_fast.cuh): st_i <- (sum_j C[i][j] X_j - m p) / 2^29, normalised.
+// One output row of small_mds (hades_fast.hpp): st_i <- (sum_j C[i][j] X_j - m p) / 2^29, normalised.
 // Same operations in the same order as row i there, hence the same limbs.
 __device__ __forceinline__ F29 small_mds_row(const int32_t *crow, const F29 (&x)[5]) {
     F29 r;

@@ -1,4 +1,4 @@
-// hades_fast.cuh -- the scale-tracked Hades252 permutation kernel (the shipped hot path).
+// hades_fast.hpp -- the scale-tracked Hades252 permutation kernel (the shipped hot path).
 //
 // Same field elements as the reference's ScalarStrategy::perm (src/strategies.rs:140-157,
 // src/strategies/scalar.rs:23-49) -- hence the same bits after the final full reduction --
@@ -27,8 +27,8 @@
 // one accumulator -- no column array).  Constants are wave-uniform: scalar loads (SMEM) into
 // SGPRs, consumed directly as multiply-add operands.
 #pragma once
-#include "fr32.cuh"
-#include "staging.cuh"
+#include "fr32.hpp"
+#include "staging.hpp"
 
 namespace hades {
 

@@ -1,7 +1,7 @@
-// hades_lanes.cuh -- the lane-split schedule: ONE field element spread over the lanes of a 16-lane DPP row,
+// hades_lanes.hpp -- the lane-split schedule: ONE field element spread over the lanes of a 16-lane DPP row,
 // one permutation per wave.
 //
-// The throughput kernel (hades_fast.cuh) and the five-waves kernel (hades_coop.cuh) keep a whole element in one lane: a
+// The throughput kernel (hades_fast.hpp) and the five-waves kernel (hades_coop.hpp) keep a whole element in one lane: a
 // Montgomery product is then ~190 DEPENDENT instructions of that lane's wave, and a lone wave issues one instruction
 // per ~4 cycles whatever it is -- that chain is what one permutation's latency is made of (the reference's real call
 // shape is ONE permutation, README.md:60-61).  Here lane k of a row holds limb k (radix 2^29, nine limbs, lanes 9..15
@@ -28,7 +28,7 @@
 // ~110 instructions per product instead of ~190, same field element: R = a b / 2^261 mod p, 0 <= R < ab/2^261 + 2.01 p.
 // tests/test_fast_model.py::lanes_* replays this file limb for limb in Python with the 64-bit column bounds asserted.
 #pragma once
-#include "hades_fast.cuh"
+#include "hades_fast.hpp"
 
 namespace hades {
 
@@ -55,7 +55,7 @@ __device__ __forceinline__ uint32_t row_bcast(uint32_t v) {
 
 // one unsigned limb product accumulated in place: a single v_mad_u64_u32.  The empty asm gives every partial sum a second
 // use, which stops LLVM's reassociation from rebuilding a column as (p1 + p2 + ...) + init with an extra 64-bit add
-// (see `pin` in hades_fast.cuh).  It is volatile on purpose: the multiply-adds then stay in SOURCE order, and the
+// (see `pin` in hades_fast.hpp).  It is volatile on purpose: the multiply-adds then stay in SOURCE order, and the
 // source order of lane_mont_mul_n is the hand-made schedule (measured: letting the scheduler move them costs 5 %).
 __device__ __forceinline__ void umac(uint64_t &acc, uint32_t a, uint32_t b) {
     acc += (uint64_t)a * b;
@@ -253,7 +253,7 @@ __device__ __forceinline__ uint32_t wave_bcast_row(uint32_t v) {
 }
 
 // One output row of the small-integer linear layer followed by the one-limb Montgomery step (small_mds_row of
-// hades_coop.cuh in lane form):  y = (sum_j c_j x_j + m p) / 2^29,  m = -Y_0 mod 2^29.
+// hades_coop.hpp in lane form):  y = (sum_j c_j x_j + m p) / 2^29,  m = -Y_0 mod 2^29.
 // x[j]: limb k of word j in lane k; c[j] < 2^17; pk = limb k of p in lane k (zero in lanes 9..15).
 // Columns < 5 * 2^17 * 2^30 + 2^58 < 2^59; result limbs <= 2^29 + 2, top limb < 2^24.
 __device__ __forceinline__ uint32_t lane_mds_row(const uint32_t (&c)[5], const uint32_t (&x)[5], uint32_t pk) {
@@ -269,7 +269,7 @@ __device__ __forceinline__ uint32_t lane_mds_row(const uint32_t (&c)[5], const u
 
 // ---- one permutation per wave ---------------------------------------------------------------------------------
 // The four rows of a wave hold the five words of ONE state: register A = words {4, 0, 1, 2} in rows {0, 1, 2, 3},
-// register B = word 3 (row 1 is the copy that counts; the other rows compute along).  The schedule is hades_coop.cuh's
+// register B = word 3 (row 1 is the copy that counts; the other rows compute along).  The schedule is hades_coop.hpp's
 // (hades252_amd/_derive.py::coop_schedule: every round moves the common scale s -> s^5 / Rp^4 / (lam 2^29)):
 //   full round     A <- S-box(A + c) in all four rows at once, then B <- S-box(B + c): 6 products
 //   partial round  three product slots: row 0 runs the S-box of word 4 (x^2, x^4, x x^4) while rows 1..3 lift words

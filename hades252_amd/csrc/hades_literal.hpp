@@ -1,4 +1,4 @@
-// hades_literal.cuh -- the permutation exactly as the reference schedules it.
+// hades_literal.hpp -- the permutation exactly as the reference schedules it.
 //
 // One permutation per lane, state (5 x 8 u32 = 40 VGPRs) in registers across all 67 rounds.
 // Every step mirrors the reference one to one, on Montgomery-form values:
@@ -9,10 +9,10 @@
 //   quintic_s_box        src/strategies/scalar.rs:32-34   (v^2)^2 * v
 //   mul_matrix           src/strategies/scalar.rs:36-49   dense 5x5, result[k] += M[k][j]*v[j]
 // 25 + 3 (or 15) full Montgomery products per round.  This is the parity anchor for the
-// scale-tracked fast kernel (hades_fast.cuh), which computes the same field elements with
+// scale-tracked fast kernel (hades_fast.hpp), which computes the same field elements with
 // ~4x fewer multiplies.
 #pragma once
-#include "fr32.cuh"
+#include "fr32.hpp"
 
 namespace hades {
 

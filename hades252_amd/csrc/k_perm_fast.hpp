@@ -1,10 +1,10 @@
-// k_perm_fast.cuh -- the shipped hot path as a kernel: one permutation per lane, scale-tracked formulation
-// (hades_fast.cuh), AoS records moved through the wave's LDS slab (staging.cuh).  Kept in a file of its own so that
+// k_perm_fast.hpp -- the shipped hot path as a kernel: one permutation per lane, scale-tracked formulation
+// (hades_fast.hpp), AoS records moved through the wave's LDS slab (staging.hpp).  Kept in a file of its own so that
 // the committed profiles of THIS kernel (profiles/hbm_traffic.json) are keyed to exactly the sources that determine
 // it (hades252_amd/build.py::perm_fast_hash).  Include after hades_constants.inc.
 #pragma once
-#include "hades_fast.cuh"
-#include "staging.cuh"
+#include "hades_fast.hpp"
+#include "staging.hpp"
 
 namespace hades {
 

@@ -1,4 +1,4 @@
-// staging.cuh -- coalesced AoS <-> per-lane record movement through LDS.
+// staging.hpp -- coalesced AoS <-> per-lane record movement through LDS.
 //
 // A batch is an array of 160-byte records (5 x BlsScalar, reference `&mut [BlsScalar]` with
 // len == WIDTH, src/strategies.rs:140).  One lane owns one record, so a wave owns 64 records =
@@ -10,7 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "fr32.cuh"
+#include "fr32.hpp"
 
 namespace hades {
 

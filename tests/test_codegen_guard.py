@@ -1,6 +1,6 @@
 """CPU tier: regression guard on the code hipcc generates for the hot kernels (no GPU needed).
 
-The shipped kernel's speed rests on two compiler-facing tricks in hades_fast.cuh (`pin`, `limb_fence`): with
+The shipped kernel's speed rests on two compiler-facing tricks in hades_fast.hpp (`pin`, `limb_fence`): with
 them every limb product is ONE `v_mad_i64_i32`; without them LLVM widens limbs to 64 bits (two multiply-adds
 and two moves per product) or re-associates column sums (an extra 64-bit add per column).  A ROCm bump could
 silently undo either.  This test compiles the device code to assembly for gfx950 and asserts, per kernel:

@@ -1,4 +1,4 @@
-"""CPU tier: a limb-exact Python replay of the scale-tracked kernel (hades_fast.cuh) with the
+"""CPU tier: a limb-exact Python replay of the scale-tracked kernel (hades_fast.hpp) with the
 machine-word bounds asserted on every intermediate, checked against the spec oracle.
 
 Random GPU tests cannot show that a 64-bit column never overflows; this model asserts it on real
@@ -32,7 +32,7 @@ def check_acc(acc):
 
 
 def mont_fips(a, b, sqr=False):
-    """mont_fips of hades_fast.cuh (signed digits): normalised limbs of a value
+    """mont_fips of hades_fast.hpp (signed digits): normalised limbs of a value
     == a*b/2^261 (mod p) in (a*b/Rp - p, a*b/Rp]."""
     assert all(-LAZY < x < LAZY for x in a + b), "|input limb| must be < 1.5 * 2^29"
     assert abs(val(a)) < (1 << 257) and abs(val(b)) < (1 << 257)
@@ -107,7 +107,7 @@ def normalised(x):
 
 
 def finalize_model(x, factor):
-    """finalize(mont_mul_const(x, factor)) of hades_fast.cuh -> fully reduced integer."""
+    """finalize(mont_mul_const(x, factor)) of hades_fast.hpp -> fully reduced integer."""
     v = val(mont_fips(x, D.to_limbs29(factor)))
     assert -2 * P < v < P
     v += 2 * P                       # + 2p, then two conditional subtractions
@@ -184,7 +184,7 @@ def test_trace_model_matches_spec_oracle():
 
 
 def small_mds_row(i, st):
-    """small_mds_row of hades_coop.cuh: one output row, same arithmetic as row i of small_mds."""
+    """small_mds_row of hades_coop.hpp: one output row, same arithmetic as row i of small_mds."""
     acc = sum(st[j][0] * D.MDS_SMALL[i][j] for j in range(5))
     check_acc(acc)
     m = acc & MASK
@@ -201,7 +201,7 @@ def small_mds_row(i, st):
 
 
 def coop_perm_model(mont_vals):
-    """Limb-exact replay of k_perm_coop (hades_coop.cuh): every word on its own wave; partial rounds scale
+    """Limb-exact replay of k_perm_coop (hades_coop.hpp): every word on its own wave; partial rounds scale
     words 0..3 up (G_r) instead of scaling word 4 down."""
     co = D.coop_schedule()
     st = [D.to_limbs29(v) for v in mont_vals]
@@ -386,7 +386,7 @@ def test_other_loader_reading_is_one_flag_away(monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------
-# lane-split schedule (csrc/hades_lanes.cuh): one field element on the 16 lanes of a DPP row, all-unsigned arithmetic.
+# lane-split schedule (csrc/hades_lanes.hpp): one field element on the 16 lanes of a DPP row, all-unsigned arithmetic.
 # The model keeps a row as a list of 16 lane values and replays every statement of lane_mont_mul_n / lane_mds_row /
 # lanes_perm with the machine-word bounds asserted (u64 columns, u32 limbs).
 # ---------------------------------------------------------------------------------------------
@@ -418,7 +418,7 @@ def u32(x):
 
 
 def carry_split(acc):
-    """carry_split of hades_lanes.cuh -> (limbs, c16, c17)."""
+    """carry_split of hades_lanes.hpp -> (limbs, c16, c17)."""
     lo = [a & MASK for a in acc]
     mid = [(a >> LB) & MASK for a in acc]
     tp = [a >> 58 for a in acc]
@@ -439,7 +439,7 @@ def lane_val(v):
 
 
 def lane_mont_mul(a, b):
-    """lane_mont_mul_n<1> of hades_lanes.cuh: a, b = 16-lane rows (limb k in lane k); returns the row of a value
+    """lane_mont_mul_n<1> of hades_lanes.hpp: a, b = 16-lane rows (limb k in lane k); returns the row of a value
     == a*b/2^261 (mod p) in [0, a*b/2^261 + 2.01 p)."""
     assert all(0 <= x <= LANE_IN_MAX for x in a + b) and lane_val(a) < (1 << 258) and lane_val(b) < (1 << 258)
     acc = [0] * 16
@@ -461,7 +461,7 @@ def lane_mont_mul(a, b):
         acc = [u64(c + x * P29[i]) for c, x in zip(acc, row_shr(m, i))]
     top = [u64(x + y * P29[NL - 1]) for x, y in zip(top, row_shl(m, 8))]
     w1, c16b, c17b = carry_split(acc)
-    assert c17a[15] == 0 and c17b[15] == 0, "column 15 never reaches bit 58 (hades_lanes.cuh drops c17)"
+    assert c17a[15] == 0 and c17b[15] == 0, "column 15 never reaches bit 58 (hades_lanes.hpp drops c17)"
     w, c16c = carry_light(w1)
     assert all(x <= (1 << LB) + 2 for x in w)
     low = val(w[:NL])
@@ -488,7 +488,7 @@ def lane_sbox(v):
 
 
 def lane_mds_row(c, xs):
-    """lane_mds_row of hades_lanes.cuh: (sum_j c_j x_j + m p) / 2^29, m = -Y_0 mod 2^29."""
+    """lane_mds_row of hades_lanes.hpp: (sum_j c_j x_j + m p) / 2^29, m = -Y_0 mod 2^29."""
     y = [0] * 16
     for j in range(5):
         y = [u64(a + x * c[j]) for a, x in zip(y, xs[j])]
@@ -506,7 +506,7 @@ def lane_mds_row(c, xs):
 
 
 def lanes_perm_model(mont_vals):
-    """Limb-exact replay of lanes_perm (hades_lanes.cuh): the coop schedule on rows, plain-limb round constants."""
+    """Limb-exact replay of lanes_perm (hades_lanes.hpp): the coop schedule on rows, plain-limb round constants."""
     co = D.coop_schedule()
     row_of = lambda v: D.to_limbs29(v) + [0] * 7
     st = [row_of(v) for v in mont_vals]

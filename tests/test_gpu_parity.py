@@ -431,7 +431,7 @@ def test_merkle_sharded_emulated(torch_cuda, H, oracle):
 
 def test_per_op_kernels_edge_values(torch_cuda, H, oracle):
     """Field-operation edge cases through the per-op kernels: operands 0, 1, p-1, p-2, R, values
-    that make word + constant cross p, etc. (saturated 8x32 arithmetic of csrc/fr32.cuh)."""
+    that make word + constant cross p, etc. (saturated 8x32 arithmetic of csrc/fr32.hpp)."""
     torch = torch_cuda
     rng = random.Random(77)
     edge = [0, 1, 2, P - 1, P - 2, R, P - R, (1 << 255) % P, P - (1 << 32), 0xFFFFFFFF, 0xFFFFFFFF00000000,

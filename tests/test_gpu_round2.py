@@ -50,7 +50,7 @@ def scalars_dev(torch, ints):
 def test_mds_blob_through_device_field_ops(torch_cuda, H, impl):
     """assets/mds.bin (written by the real dusk-bls12_381, HOWTO.md:71-108) regenerated with the DEVICE
     field arithmetic: x = from(i) + from(j+5) via from_raw and add, x^(p-2) by ~380 device squarings /
-    products.  impl 0 = fr32.cuh (literal kernels), impl 1 = to_f29 / mont_fips / finalize (shipped kernel)."""
+    products.  impl 0 = fr32.hpp (literal kernels), impl 1 = to_f29 / mont_fips / finalize (shipped kernel)."""
     torch = torch_cuda
     xs = H.fr_op(H.FR_FROM_RAW, scalars_dev(torch, [i for i in range(5) for _ in range(5)]), impl=impl)
     ys = H.fr_op(H.FR_FROM_RAW, scalars_dev(torch, [j + 5 for _ in range(5) for j in range(5)]), impl=impl)

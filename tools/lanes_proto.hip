@@ -1,4 +1,4 @@
-// lanes_proto.hip -- the lane-split Montgomery product (hades_lanes.cuh) against the per-lane one (mont_fips):
+// lanes_proto.hip -- the lane-split Montgomery product (hades_lanes.hpp) against the per-lane one (mont_fips):
 // (1) same field element on random and edge operands, (2) time of a dependent chain in ONE wave.
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Ihades252_amd/csrc -o build_tools/lanes_proto tools/lanes_proto.hip
 #include <hip/hip_runtime.h>
@@ -8,8 +8,8 @@
 #include <chrono>
 #include <vector>
 #include "hades_constants.inc"
-#include "hades_fast.cuh"
-#include "hades_lanes.cuh"
+#include "hades_fast.hpp"
+#include "hades_lanes.hpp"
 using namespace hades;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 

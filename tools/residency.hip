@@ -1,6 +1,6 @@
 // residency.hip -- residency sweep of the shipped permutation kernel.
 //
-// Same device code as k_perm_fast (hades_fast.cuh + staging.cuh), instantiated with different block sizes,
+// Same device code as k_perm_fast (hades_fast.hpp + staging.hpp), instantiated with different block sizes,
 // launch bounds and LDS footprints, so that the number of co-resident waves per SIMD varies from 1 to 5
 // while everything else stays fixed.  For every variant: VGPRs (hipFuncGetAttributes), LDS per block,
 // blocks per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor) -> waves per SIMD, and the time for 2^24
@@ -14,7 +14,7 @@
 #include <algorithm>
 #include <vector>
 #include "hades_constants.inc"
-#include "hades_fast.cuh"
+#include "hades_fast.hpp"
 
 using namespace hades;
 

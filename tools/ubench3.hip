@@ -22,7 +22,7 @@
 #include <map>
 #include <vector>
 #include "hades_constants.inc"
-#include "hades_fast.cuh"
+#include "hades_fast.hpp"
 
 using namespace hades;
 
