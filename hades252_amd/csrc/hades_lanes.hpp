@@ -18,12 +18,13 @@
 // Between the stages the 64-bit column sums go back to limbs in ONE lane-parallel step of 32-bit operations: a column
 // is cut into bits 0..28 / 29..57 / 58..63, the middle piece moves one lane up and the top piece two -- limbs come out
 // LAZY (below 2^30 + 64), which is all a multiply-add operand needs; nothing is ever propagated serially across the
-// row.  The final result takes one more light pass (limbs <= 2^29 + 2) so that two such values can be multiplied.
+// row.  A product's result keeps those lazy limbs: 9 (2^30 + 66)^2 still fits 64 bits, so x^2 and x^4 go straight into
+// the next product; only the linear layer (whose output meets a round key before it is squared) normalises to 2^29 + 2.
 // 17 columns (0..16) on 16 lanes: column 16 (and 17, times 2^29) lives in lane 0 of a 64-bit "top" accumulator, zero
 // in every other lane by construction (it is only ever fed by row_shl:8 / row_shl:15 moves, which zero-fill).
-// Exact division by 2^261: after the passes the nine low limbs represent 0 or 2^261 exactly (their value is
-// congruent to 0 and below 2^261 (1 + 2^-27)); 0 means all nine are zero, 2^261 shows as limb 8 >= 2^29 - 1 and is
-// carried.
+// Exact division by 2^261: after the carry step the nine low limbs represent 0, 2^261 or 2 * 2^261 exactly (their value
+// is congruent to 0 and below 2^262 (1 + 2^-24)); limb 8 alone tells which (it is c 2^29 minus at most 3), and c is
+// carried into limb 9.
 //
 // ~110 instructions per product instead of ~190, same field element: R = a b / 2^261 mod p, 0 <= R < ab/2^261 + 2.01 p.
 // tests/test_fast_model.py::lanes_* replays this file limb for limb in Python with the 64-bit column bounds asserted.
@@ -130,9 +131,9 @@ __device__ __forceinline__ uint32_t carry_light(uint32_t t, uint32_t &c16) {
 // N independent products side by side, R[n] = a[n] b[n] / 2^261 (mod p): the statements of the N chains alternate, so
 // one chain's instructions fill the wait states the other's DPP moves and multiply-adds need (a lone chain spends a
 // tenth of its issue slots in s_nop).
-// a, b: lane k = limb k (k < 9), lanes 9..15 zero, limbs <= 2^30 + 1, values < 2^257.
+// a, b: lane k = limb k (k < 9), lanes 9..15 zero, limbs <= 2^30 + 66, values < 2^257.
 // as = lane_bcasts(a), bs = lane_shifts(b): kept by the caller when an operand is used again (x^5 = x * x^4 reuses
-// the broadcasts of x).  Result limbs <= 2^29 + 2 (limb 8 < 2^26), 0 <= R < ab/2^261 + 2.01 p.
+// the broadcasts of x).  Result limbs <= 2^30 + 66 (limb 8 < 2^26), 0 <= R < ab/2^261 + 2.01 p.
 template <int N>
 __device__ __forceinline__ void lane_mont_mul_n(const LaneConsts &K, const LaneForms (&as)[N], const uint32_t (&b)[N],
                                                 const LaneForms (&bs)[N], uint32_t (&out)[N]) {
@@ -183,16 +184,16 @@ __device__ __forceinline__ void lane_mont_mul_n(const LaneConsts &K, const LaneF
 #pragma unroll
     for (int n = 0; n < N; n++) {
         umac(top[n], row_shl<8>(m[n]), K.p[kNL - 1]);                // column 16: + m_8 p_8 (lane 0)
-        uint32_t c16b, c16c;
-        const uint32_t w1 = carry_split(acc[n], c16b, c17[n]);
-        uint32_t w = carry_light(w1, c16c);
-        // residual carry of the low part into limb 9: lane 8 holds 0 (then the whole low part is 0) or ~2^29
-        const uint32_t z = lane == kNL - 1 ? (w < 1u ? w : 1u) : 0;
+        uint32_t c16b;
+        uint32_t w = carry_split(acc[n], c16b, c17[n]);
+        // residual carry of the low part into limb 9: the nine low limbs (each < 2^30 + 64) represent 0, 2^261 or
+        // 2 * 2^261 exactly, and limb 8 alone tells which: it is c 2^29 minus at most 3
+        const uint32_t z = lane == kNL - 1 ? (w + 3u) >> kLB : 0;
         w += row_shr<1>(z);
         // ---- column 16: everything that left lane 15, collected in lane 0.  Nothing reaches column 17 directly: column
         // 15 holds two products with a top limb (a_7 b_8 + a_8 b_7 < 2^57, t_15 + m_7 p_8 + m_8 p_7 < 2^58), so its top
         // piece (c17) is zero.
-        umac(top[n], row_shl<15>(c16a[n] + c16b + c16c), 1);
+        umac(top[n], row_shl<15>(c16a[n] + c16b), 1);
         // ---- R: limbs 0..6 = lanes 9..15 of w, limb 7 = low 29 bits of top, limb 8 = the rest (small)
         const uint32_t tlo = (uint32_t)top[n], thi = (uint32_t)(top[n] >> 32);
         const uint32_t r7 = tlo & kMask29;                           // zero outside lane 0
@@ -255,7 +256,7 @@ __device__ __forceinline__ uint32_t wave_bcast_row(uint32_t v) {
 // One output row of the small-integer linear layer followed by the one-limb Montgomery step (small_mds_row of
 // hades_coop.hpp in lane form):  y = (sum_j c_j x_j + m p) / 2^29,  m = -Y_0 mod 2^29.
 // x[j]: limb k of word j in lane k; c[j] < 2^17; pk = limb k of p in lane k (zero in lanes 9..15).
-// Columns < 5 * 2^17 * 2^30 + 2^58 < 2^59; result limbs <= 2^29 + 2, top limb < 2^24.
+// Columns < 5 * 2^17 * (2^30 + 66) + 2^58 < 2^59; result limbs <= 2^29 + 2, top limb < 2^24.
 __device__ __forceinline__ uint32_t lane_mds_row(const uint32_t (&c)[5], const uint32_t (&x)[5], uint32_t pk) {
     uint64_t y = 0;
 #pragma unroll

@@ -392,7 +392,7 @@ def test_other_loader_reading_is_one_flag_away(monkeypatch):
 # ---------------------------------------------------------------------------------------------
 U64, U32 = 1 << 64, 1 << 32
 PINV29 = D.to_limbs29((-pow(P, -1, D.RP)) % D.RP)
-LANE_IN_MAX = (1 << 30) + 1            # operand limb bound of the lane product
+LANE_IN_MAX = (1 << 30) + 66           # operand limb bound of the lane product (a product's own lazy output)
 
 
 def row_shr(v, n):
@@ -460,16 +460,14 @@ def lane_mont_mul(a, b):
     for i in range(NL):
         acc = [u64(c + x * P29[i]) for c, x in zip(acc, row_shr(m, i))]
     top = [u64(x + y * P29[NL - 1]) for x, y in zip(top, row_shl(m, 8))]
-    w1, c16b, c17b = carry_split(acc)
+    w, c16b, c17b = carry_split(acc)
     assert c17a[15] == 0 and c17b[15] == 0, "column 15 never reaches bit 58 (hades_lanes.hpp drops c17)"
-    w, c16c = carry_light(w1)
-    assert all(x <= (1 << LB) + 2 for x in w)
     low = val(w[:NL])
-    assert low in (0, D.RP), "the low nine limbs cancel to 0 or 2^261"
-    assert (low == 0) == (w[NL - 1] == 0)
-    z = [min(w[k], 1) if k == NL - 1 else 0 for k in range(16)]
+    assert low in (0, D.RP, 2 * D.RP), "the low nine limbs cancel to 0, 2^261 or 2 * 2^261"
+    z = [(w[k] + 3) >> LB if k == NL - 1 else 0 for k in range(16)]
+    assert z[NL - 1] * D.RP == low, "limb 8 alone tells the residual carry"
     w = [u32(x + y) for x, y in zip(w, row_shr(z, 1))]
-    top = [u64(x + y) for x, y in zip(top, row_shl([u32(p + q + r) for p, q, r in zip(c16a, c16b, c16c)], 15))]
+    top = [u64(x + y) for x, y in zip(top, row_shl([u32(p + q) for p, q in zip(c16a, c16b)], 15))]
     assert all(x == 0 for x in top[1:])
     r7 = [x & MASK for x in top]
     r8 = [u32(x >> LB) for x in top]
@@ -477,7 +475,7 @@ def lane_mont_mul(a, b):
     ab = lane_val(a) * lane_val(b)
     r = lane_val(out)
     assert r * D.RP == ab + val(m[:NL]) * P, "R = (ab + M p) / 2^261 exactly"
-    assert r < ab // D.RP + 2 * P + (P >> 20) and all(x <= (1 << LB) + 2 for x in out) and out[NL - 1] < (1 << 26)
+    assert r < ab // D.RP + 2 * P + (P >> 20) and all(x <= LANE_IN_MAX for x in out) and out[NL - 1] < (1 << 26)
     return out
 
 
@@ -495,7 +493,7 @@ def lane_mds_row(c, xs):
     m = ((0 - y[0]) % U32) & MASK
     pk = P29 + [0] * 7
     y = [u64(a + m * q) for a, q in zip(y, pk)]
-    assert all(a < (1 << 59) for a in y) and y[0] & MASK == 0
+    assert all(a < (1 << 59) for a in y) and y[0] & MASK == 0 and all(x <= LANE_IN_MAX for v in xs for x in v)
     t = [u32((a & MASK) + b) for a, b in zip(y, row_shr([(a >> LB) & (U32 - 1) for a in y], 1))]
     w, _ = carry_light(t)
     assert w[0] == 0
@@ -539,7 +537,8 @@ def test_lanes_product_bounds_adversarial():
     rng = random.Random(47)
     top = (1 << 25) - 1                                   # value < 2^258 (the kernel's values stay below 2^257)
     pats = [[LANE_IN_MAX] * (NL - 1) + [top], [MASK] * (NL - 1) + [top], [0] * NL, [1] + [0] * (NL - 1),
-            [0] * (NL - 1) + [top], [LANE_IN_MAX, 0] * 4 + [top], [(1 << LB) + 2] * (NL - 1) + [top]]
+            [0] * (NL - 1) + [top], [LANE_IN_MAX, 0] * 4 + [top], [(1 << LB) + 2] * (NL - 1) + [top],
+            [(1 << 30) + 1] * (NL - 1) + [top]]
     pats += [[rng.randrange(LANE_IN_MAX + 1) for _ in range(NL - 1)] + [rng.randrange(top)] for _ in range(40)]
     rows = [p + [0] * 7 for p in pats]
     for a in rows:
@@ -547,7 +546,7 @@ def test_lanes_product_bounds_adversarial():
             r = lane_mont_mul(a, b)
             assert lane_val(r) % P == lane_val(a) * lane_val(b) * pow(D.RP, -1, P) % P
     # linear layer at its maxima
-    big = [(1 << LB) + 2] * (NL - 1) + [(1 << 26) - 1] + [0] * 7          # the result bound of a product
+    big = [LANE_IN_MAX] * (NL - 1) + [(1 << 26) - 1] + [0] * 7             # the result bound of a product
     for i in range(5):
         lane_mds_row(D.MDS_SMALL[i], [big] * 5)
         lane_mds_row(D.MDS_SMALL[i], [rows[0]] * 5)          # even straight after a round key
