@@ -499,36 +499,63 @@ __global__ void __launch_bounds__(kCoopThreads) k_perm_coop(uint8_t *states, siz
 }
 
 // ---- lowest-latency kernels: one state per WAVE, every field element spread over a 16-lane row (hades_lanes.hpp) ---
-constexpr int kLanesWaves = 4;                   // states per block
-// In-place permutation, one state per wave (no block-wide barrier anywhere: idle waves simply leave).
+// Two forms, four waves per block (one per SIMD) either way:
+//   HELPED   three states per block + a helper wave that owns word 3 of all three during the full rounds (its S-box then
+//            runs beside the main waves' instead of doubling their instruction stream): 50 us -- up to 768 states, one
+//            block per CU;
+//   plain    four states per block, every wave does everything itself: 54 us -- for 769 .. 1 024 states, where the helped
+//            form would put a second block on some CUs.
+constexpr int kLanesWaves = 4;
+template <bool HELPED>
+__device__ __forceinline__ bool lanes_role(LanesLds *L, size_t n, size_t &rec) {        // false: this wave is done
+    const int wave = threadIdx.x >> 6;
+    if constexpr (HELPED) {
+        if (wave == kLanesWaves - 1) {
+            lanes_helper<kLanesWaves - 1>(&d_lanes, *reinterpret_cast<LanesLds(*)[kLanesWaves - 1]>(L));
+            return false;
+        }
+        rec = (size_t)blockIdx.x * (kLanesWaves - 1) + wave;
+        if (rec >= n) {
+            lanes_idle();
+            return false;
+        }
+        return true;
+    } else {
+        rec = (size_t)blockIdx.x * kLanesWaves + wave;
+        return rec < n;                                              // no block-wide barrier anywhere: idle waves leave
+    }
+}
+
+// In-place permutation, one state per wave.
+template <bool HELPED>
 __global__ void __launch_bounds__(kLanesWaves *kWave) k_perm_lanes(uint8_t *states, size_t n) {
     __shared__ LanesLds L[kLanesWaves];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
-    const size_t rec = (size_t)blockIdx.x * kLanesWaves + wave;
-    if (rec >= n) return;
+    size_t rec;
+    if (!lanes_role<HELPED>(L, n, rec)) return;
     uint8_t *mine = states + rec * 160 + (lane < 5 ? lane : 0) * 32;
     const Fr in = lane < 5 ? load_word(mine) : zero_word();
-    const Fr out = lanes_perm(&d_lanes, L[wave], in);
+    const Fr out = lanes_perm<HELPED>(&d_lanes, L[wave], in);
     if (lane < 5) store_word(mine, out);
 }
 
 // One Merkle level, one parent per wave: parent = perm([tag, c_0 .. c_{ARITY-1}, 0 ..])[out_idx]; ragged levels and
 // `pad` as in k_merkle_level_fast.
-template <int ARITY>
+template <int ARITY, bool HELPED>
 __global__ void __launch_bounds__(kLanesWaves *kWave) k_merkle_lanes(const uint8_t *__restrict__ children, size_t n_children,
                                                                      uint8_t *__restrict__ parents, size_t n_parents,
                                                                      Fr tag, int out_idx, const uint8_t *__restrict__ pad) {
     __shared__ LanesLds L[kLanesWaves];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
-    const size_t rec = (size_t)blockIdx.x * kLanesWaves + wave;
-    if (rec >= n_parents) return;
+    size_t rec;
+    if (!lanes_role<HELPED>(L, n_parents, rec)) return;
     Fr in = zero_word();
     if (lane == 0) in = tag;
     if (lane >= 1 && lane <= ARITY) {
         const size_t c = rec * ARITY + (lane - 1);
         in = c < n_children ? load_word(children + c * 32) : load_pad(pad);
     }
-    const Fr out = lanes_perm(&d_lanes, L[wave], in);
+    const Fr out = lanes_perm<HELPED>(&d_lanes, L[wave], in);
     if (lane == out_idx) store_word(parents + rec * 32, out);
 }
 
@@ -953,6 +980,8 @@ static constexpr size_t kCoopMaxStates = (size_t)1 << 14;
 // ... and one this small (at most one wave per SIMD) is fastest with one state per wave, every product spread over a
 // 16-lane row (hades_lanes.hpp): about half the latency of the five-waves kernel
 static constexpr size_t kLanesMaxStates = (size_t)1 << 10;
+// ... with a helper wave per three states while that still means one block per CU (256 CUs x 3)
+static constexpr size_t kLanesHelpedMaxStates = 768;
 
 // one parent per lane (any size, any arity, ragged levels)
 static void launch_merkle_level(int arity, const uint8_t *children, size_t n_children, uint8_t *parents, size_t n, Fr tag,
@@ -972,9 +1001,18 @@ static void launch_merkle_level(int arity, const uint8_t *children, size_t n_chi
 // one parent per wave (small levels: lowest latency)
 static void launch_merkle_lanes(int arity, const uint8_t *children, size_t n_children, uint8_t *parents, size_t n, Fr tag,
                                 int out_idx, const uint8_t *pad, hipStream_t s) {
-    const dim3 grid((unsigned)((n + kLanesWaves - 1) / kLanesWaves)), block(kLanesWaves * kWave);
-#define HADES_LAUNCH_LANES(A) \
-    hipLaunchKernelGGL(k_merkle_lanes<A>, grid, block, 0, s, children, n_children, parents, n, tag, out_idx, pad)
+    const bool helped = n <= kLanesHelpedMaxStates;
+    const unsigned per_block = helped ? kLanesWaves - 1 : kLanesWaves;
+    const dim3 grid((unsigned)((n + per_block - 1) / per_block)), block(kLanesWaves * kWave);
+#define HADES_LAUNCH_LANES(A)                                                                                          \
+    do {                                                                                                               \
+        if (helped)                                                                                                    \
+            hipLaunchKernelGGL((k_merkle_lanes<A, true>), grid, block, 0, s, children, n_children, parents, n, tag,   \
+                               out_idx, pad);                                                                          \
+        else                                                                                                           \
+            hipLaunchKernelGGL((k_merkle_lanes<A, false>), grid, block, 0, s, children, n_children, parents, n, tag,  \
+                               out_idx, pad);                                                                          \
+    } while (0)
     switch (arity) {
         case 1: HADES_LAUNCH_LANES(1); break;
         case 2: HADES_LAUNCH_LANES(2); break;
@@ -1066,8 +1104,12 @@ int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int
     for (size_t off = 0; off < n_perms; off += kMaxLaunchRecords) {
         size_t n = n_perms - off < kMaxLaunchRecords ? n_perms - off : kMaxLaunchRecords;
         if (kernel == HADES252_KERNEL_LANES) {
-            hipLaunchKernelGGL(k_perm_lanes, dim3((unsigned)((n + kLanesWaves - 1) / kLanesWaves)),
-                               dim3(kLanesWaves * kWave), 0, s, p + off * 160, n);
+            if (n <= kLanesHelpedMaxStates)
+                hipLaunchKernelGGL(k_perm_lanes<true>, dim3((unsigned)((n + kLanesWaves - 2) / (kLanesWaves - 1))),
+                                   dim3(kLanesWaves * kWave), 0, s, p + off * 160, n);
+            else
+                hipLaunchKernelGGL(k_perm_lanes<false>, dim3((unsigned)((n + kLanesWaves - 1) / kLanesWaves)),
+                                   dim3(kLanesWaves * kWave), 0, s, p + off * 160, n);
         } else if (kernel == HADES252_KERNEL_COOP) {
             hipLaunchKernelGGL(k_perm_coop, dim3((unsigned)((n + kCoopStates - 1) / kCoopStates)), dim3(kCoopThreads), 0,
                                s, p + off * 160, n);

@@ -297,9 +297,20 @@ __device__ __forceinline__ void lanes_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Number of block-wide barriers a helped main wave / the helper wave / an idle wave of the block goes through:
+// input hand-over, one per full round (8), the hand-over of word 3 before the trailing full rounds, output hand-over.
+constexpr int kLanesBarriers = 11;
+
 // in: this wave's state as five BlsScalars in lanes 0..4 (lane w = word w; other lanes ignored);
 // out: the permuted words, fully reduced, in lanes 0..4.
+// HELPED = false: the wave does everything itself (register B = word 3 runs its S-box interleaved with A's in the full
+//   rounds).  HELPED = true: a helper wave of the same block (lanes_helper) owns word 3 during the eight full rounds --
+//   its S-box then runs on another SIMD at the same time instead of doubling this wave's instruction stream; the two
+//   meet at one block-wide barrier per full round (the words are exchanged through this state's LDS area anyway), and
+//   word 3 changes hands before round 4 (this wave computes its row itself in round 3), before round 63 and at the end.
+//   Every wave of the block must then pass kLanesBarriers barriers.
 // stamps (diagnostic builds only, tools/lanes_proto.hip): shader-clock readings after the input stage and after the rounds
+template <bool HELPED>
 __device__ __forceinline__ Fr lanes_perm(const LanesTables *T, LanesLds &L, const Fr &in,
                                          unsigned long long *stamps = nullptr) {
     const int lane = threadIdx.x & 63, row = lane >> 4, k = lane & 15;
@@ -328,28 +339,33 @@ __device__ __forceinline__ Fr lanes_perm(const LanesTables *T, LanesLds &L, cons
         for (int i = 0; i < 16; i++) L.io[lane][i] = i < kNL ? (uint32_t)f.l[i] : 0u;
     }
     lanes_fence();
+    if constexpr (HELPED) __syncthreads();                           // the helper picks up word 3
     uint32_t A = L.io[word_a][k], B = L.io[3][k];
-    // round r's three constants of this lane sit at rec[off_*]; rec advances by one 256-byte record per round (a scalar
-    // pointer: the per-lane part of the address never changes)
+    // round r's constants of this lane sit at rec[off_*]; rec advances by one 256-byte record per round (a scalar
+    // pointer: the per-lane part of the address never changes); every round fetches the next round's constants first
     const uint32_t *rec = &T->round[0][0];
     uint32_t c_a = rec[off_a], c_b = rec[off_b], c_g = rec[off_g];
     if (stamps != nullptr) {
         asm volatile("" : "+v"(A), "+v"(B), "+v"(c_a), "+v"(c_b), "+v"(c_g));
         stamps[0] = __builtin_amdgcn_s_memtime();
     }
-#pragma unroll 1
-    for (int r = 0; r < 67; r++) {
-        const bool full = r < 4 || r >= 63;
-        rec += 64;                                                   // next round's constants, fetched now
+    // Three loops (4 full, 59 partial, 4 full rounds: src/strategies.rs:144-156), each with a straight-line body.
+    auto full_round = [&](bool take_word3) {
+        rec += 64;
         const uint32_t n_a = rec[off_a], n_b = rec[off_b], n_g = rec[off_g];
         unsigned long long ts0 = 0, ts1 = 0;
         if (stamps != nullptr) ts0 = __builtin_amdgcn_s_memtime();
-        A += c_a;
-        B += c_b;
-        // Partial round: the words that are ready early meet in LDS while word 4's last product is still running (its
-        // ~500 cycles hide the round trip); the late word crosses the rows by two half-exchanges.
         uint32_t x[5];
-        if (full) {
+        A += c_a;
+        if constexpr (HELPED) {
+            A = lane_sbox(K, A);                                                      // words 4, 0, 1, 2
+            L.xw[k][word_a] = A;
+            __syncthreads();                                                          // the helper has stored word 3
+            const uint4 q = *reinterpret_cast<const uint4 *>(&L.xw[k][0]);
+            x[4] = L.xw[k][4];
+            x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+        } else {
+            B += c_b;
             uint32_t v[2] = {A, B};                                                  // words 4, 0, 1, 2 and word 3:
             lane_sbox_n<2>(K, v);                                                     // two S-boxes, statements interleaved
             A = v[0];
@@ -360,20 +376,44 @@ __device__ __forceinline__ Fr lanes_perm(const LanesTables *T, LanesLds &L, cons
             x[4] = L.xw[k][4];
             x[0] = q.x; x[1] = q.y; x[2] = q.z;
             x[3] = wave_bcast_row<1>(B);
-        } else {
-            const LaneForms ab = lane_bcasts(A);
-            const uint32_t b1 = row0 ? A : c_g;
-            const uint32_t p1 = lane_mont_mul(K, ab, b1, lane_shifts(b1));        // row 0: x^2;  rows 1..3: w G
-            const uint32_t a2 = row0 ? p1 : B, b2 = row0 ? p1 : c_g;
-            const uint32_t p2 = lane_mont_mul(K, lane_bcasts(a2), b2, lane_shifts(b2));   // row 0: x^4;  row 1: w_3 G
-            L.xw[k][row0 ? 5 : word_a] = p1;                                          // words 0, 1, 2 (row 0 parks x^2)
-            L.xw[k][slot_b] = p2;                                                     // word 3
-            lanes_fence();
-            const uint4 q = *reinterpret_cast<const uint4 *>(&L.xw[k][0]);
-            x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
-            const uint32_t p3 = lane_mont_mul(K, ab, p2, lane_shifts(p2));        // row 0: x x^4
-            x[4] = wave_bcast_row<0>(p3);
         }
+        if (stamps != nullptr) {
+            asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]));
+            ts1 = __builtin_amdgcn_s_memtime();
+        }
+        A = lane_mds_row(ca_m, x, pk);
+        if (!HELPED || take_word3) B = lane_mds_row(cb_m, x, pk);    // helped: word 3 stays with the helper between full rounds
+        if (stamps != nullptr) {
+            asm volatile("" : "+v"(A), "+v"(B));
+            stamps[4] += ts1 - ts0;
+            stamps[5] += __builtin_amdgcn_s_memtime() - ts1;
+        }
+        c_a = n_a;
+        c_b = n_b;
+        c_g = n_g;
+        asm volatile("" : "+v"(A), "+v"(B));
+    };
+    // Partial round: the words that are ready early meet in LDS while word 4's last product is still running (its
+    // ~500 cycles hide the round trip); the late word crosses the rows by two half-exchanges.
+    auto partial_round = [&]() {
+        rec += 64;
+        const uint32_t n_a = rec[off_a], n_b = rec[off_b], n_g = rec[off_g];
+        unsigned long long ts0 = 0, ts1 = 0;
+        if (stamps != nullptr) ts0 = __builtin_amdgcn_s_memtime();
+        uint32_t x[5];
+        A += c_a;                                                                     // (words 0..3 have no constant here)
+        const LaneForms ab = lane_bcasts(A);
+        const uint32_t b1 = row0 ? A : c_g;
+        const uint32_t p1 = lane_mont_mul(K, ab, b1, lane_shifts(b1));            // row 0: x^2;  rows 1..3: w G
+        const uint32_t a2 = row0 ? p1 : B, b2 = row0 ? p1 : c_g;
+        const uint32_t p2 = lane_mont_mul(K, lane_bcasts(a2), b2, lane_shifts(b2));       // row 0: x^4;  row 1: w_3 G
+        L.xw[k][row0 ? 5 : word_a] = p1;                                              // words 0, 1, 2 (row 0 parks x^2)
+        L.xw[k][slot_b] = p2;                                                         // word 3
+        lanes_fence();
+        const uint4 q = *reinterpret_cast<const uint4 *>(&L.xw[k][0]);
+        x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+        const uint32_t p3 = lane_mont_mul(K, ab, p2, lane_shifts(p2));            // row 0: x x^4
+        x[4] = wave_bcast_row<0>(p3);
         if (stamps != nullptr) {
             asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]));
             ts1 = __builtin_amdgcn_s_memtime();
@@ -382,24 +422,88 @@ __device__ __forceinline__ Fr lanes_perm(const LanesTables *T, LanesLds &L, cons
         B = lane_mds_row(cb_m, x, pk);
         if (stamps != nullptr) {
             asm volatile("" : "+v"(A), "+v"(B));
-            const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
-            stamps[full ? 4 : 2] += ts1 - ts0;      // products + exchange
-            stamps[full ? 5 : 3] += ts2 - ts1;      // linear layer
+            stamps[2] += ts1 - ts0;
+            stamps[3] += __builtin_amdgcn_s_memtime() - ts1;
         }
         c_a = n_a;
         c_b = n_b;
         c_g = n_g;
         asm volatile("" : "+v"(A), "+v"(B));
+    };
+#pragma unroll 1
+    for (int r = 0; r < 3; r++) full_round(false);
+    full_round(true);                                                // round 3: this wave takes word 3 for the partial rounds
+#pragma unroll 1
+    for (int r = 4; r < 63; r++) partial_round();
+    if constexpr (HELPED) {                                          // word 3 goes back to the helper
+        L.xw[k][slot_b] = B;
+        __syncthreads();
     }
+#pragma unroll 1
+    for (int r = 63; r < 67; r++) full_round(false);
     if (stamps != nullptr) stamps[1] = __builtin_amdgcn_s_memtime();
     // ---- out: the words go back to one lane each for the final product and the full reduction
+    if constexpr (HELPED) __syncthreads();                           // the helper has stored the final word 3 in io[3]
     L.io[word_a][k] = A;
-    L.io[row == 1 ? 3 : 5][k] = B;
+    if constexpr (!HELPED) L.io[row == 1 ? 3 : 5][k] = B;
     lanes_fence();
     F29 f;
 #pragma unroll
     for (int i = 0; i < kNL; i++) f.l[i] = (int32_t)L.io[lane < 5 ? lane : 0][i];
     return finalize(mont_mul_const(f, T->final_f));
+}
+
+// The helper wave of a block of NSTATES helped main waves: row s owns word 3 of state s during the full rounds.
+template <int NSTATES>
+__device__ __forceinline__ void lanes_helper(const LanesTables *T, LanesLds (&Ls)[NSTATES]) {
+    const int lane = threadIdx.x & 63, row = lane >> 4, k = lane & 15;
+    LanesLds &L = Ls[row < NSTATES ? row : NSTATES - 1];            // a spare row works along on the last state ...
+    const int slot = row < NSTATES ? 3 : 7;                          // ... and parks its results in a dummy slot
+    LaneConsts K;
+#pragma unroll
+    for (int i = 0; i < kNL; i++) {
+        K.p[i] = T->p[i];
+        K.pinv[i] = T->pinv[i];
+    }
+    const int off_b = k < kNL ? 3 * kNL + k : 54;
+    uint32_t cb_m[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) cb_m[j] = T->mds[3][j];
+    const uint32_t pk = T->p16[k];
+    // word 3's round constants of the eight full rounds, fetched up front: a load issued when the constant is needed
+    // would make this wave late at every barrier
+    uint32_t cb[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) cb[i] = T->round[i < 4 ? i : 59 + i][off_b];
+    __syncthreads();                                                 // the main waves have stored their inputs
+    uint32_t H = L.io[3][k];
+#pragma unroll 1
+    for (int i = 0; i < 8; i++) {
+        if (i == 4) {                                                // partial rounds: word 3 is with the main waves
+            __syncthreads();
+            H = L.xw[k][3];
+        }
+        uint32_t c = cb[0];
+#pragma unroll
+        for (int j = 1; j < 8; j++) c = i == j ? cb[j] : c;
+        H += c;
+        H = lane_sbox(K, H);
+        L.xw[k][slot] = H;
+        __syncthreads();
+        uint32_t x[5];
+        const uint4 q = *reinterpret_cast<const uint4 *>(&L.xw[k][0]);
+        x[4] = L.xw[k][4];
+        x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+        H = lane_mds_row(cb_m, x, pk);
+        asm volatile("" : "+v"(H));
+    }
+    L.io[row < NSTATES ? 3 : 7][k] = H;
+    __syncthreads();
+}
+
+// an idle wave of a helped block (no state to work on) only keeps the barrier count
+__device__ __forceinline__ void lanes_idle() {
+    for (int i = 0; i < kLanesBarriers; i++) __syncthreads();
 }
 
 }  // namespace hades

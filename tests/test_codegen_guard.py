@@ -29,9 +29,9 @@ def device_asm(tmp_path_factory):
                        cwd=CSRC, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     text = open(out).read()
-    # kernel bodies: from "<name>:" to its s_endpgm
+    # kernel bodies: from "<name>:" to the end of the function (a kernel may hold several s_endpgm: early exits)
     bodies = {}
-    for m in re.finditer(r"^(_Z\w+):\s*; @\1\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_Z\w+):\s*; @\1\n(.*?)\n\.Lfunc_end", text, re.S | re.M):
         bodies[m.group(1)] = m.group(2)
     # resource remarks
     res, cur = {}, None
@@ -81,13 +81,17 @@ def test_perm_lanes_instruction_mix(device_asm):
     product is 28 multiply-adds (9 + 9 + 9 + the column-16 one) and ~45 DPP moves; a partial round runs 3 products, a
     full round 6.  A toolchain change that splits the 64-bit multiply-adds or doubles the DPP traffic fails here."""
     bodies, res = device_asm
-    (name,) = find(bodies, "k_perm_lanes")
-    body = bodies[name]
-    umads = len(re.findall(r"\bv_mad_u64_u32\b", body))
-    dpp = len(re.findall(r"\bv_mov_b32_dpp\b", body))
-    nops = len(re.findall(r"\bs_nop\b", body))
-    # 9 products in the two round bodies x 28 + the two linear-layer rows (6 each) + the per-lane final product
-    assert 9 * 28 <= umads <= 9 * 28 + 40, umads
-    assert dpp <= 9 * 45 + 30, dpp
-    assert nops <= 130, "%d s_nop: the hand-made interleaving of the two S-boxes of a full round got lost?" % nops
-    assert res[name]["VGPRs"] <= 96, res[name]
+    names = find(bodies, "k_perm_lanes")
+    assert len(names) == 2                      # the helped form (three states + a helper wave) and the plain one
+    for name in names:
+        body = bodies[name]
+        umads = len(re.findall(r"\bv_mad_u64_u32\b", body))
+        dpp = len(re.findall(r"\bv_mov_b32_dpp\b", body))
+        nops = len(re.findall(r"\bs_nop\b", body))
+        helped = "s_barrier" in body
+        # products in the round bodies: full (twice in the code: leading and trailing loops) + partial, x 28 multiply-adds;
+        # + the linear-layer rows (6 each), the helper's rounds and the per-lane final product
+        assert 9 * 28 <= umads <= 22 * 28 + 80, (name, umads)
+        assert dpp <= 22 * 45 + 60, (name, dpp)
+        assert nops <= (330 if helped else 260), "%s: %d s_nop: the hand-made interleaving got lost?" % (name, nops)
+        assert res[name]["VGPRs"] <= 96, res[name]

@@ -188,11 +188,12 @@ def test_multi_workers_concurrent_with_host_calls(torch_cuda, H, oracle):
 
 
 # ---------------------------------------------------------------------------------------------
-# lane-split kernel: dispatch thresholds (1 024: one state per wave; 16 384: five waves per state; above: per lane)
+# lane-split kernel: dispatch thresholds (768: one state per wave + a helper wave per three states; 1 024: one state per
+# wave; 16 384: five waves per state; above: per lane)
 # ---------------------------------------------------------------------------------------------
 def test_default_dispatch_across_both_thresholds(torch_cuda, H, oracle):
     torch = torch_cuda
-    for n in (1, 3, 4, 5, 1023, 1024, 1025, 2048, (1 << 14), (1 << 14) + 1):
+    for n in (1, 2, 3, 4, 5, 6, 7, 767, 768, 769, 1023, 1024, 1025, 2048, (1 << 14), (1 << 14) + 1):
         inp = oracle.gen_b(11 * n, 5 * n)
         guard = np.full(40, 0xDEADBEEFCAFEF00D, dtype=np.uint64)
         exp = oracle.perm_batch(inp)

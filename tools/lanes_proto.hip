@@ -106,7 +106,43 @@ __global__ void k_perm_stamped(uint8_t *state, unsigned long long *stamps) {
         in.l[4] = hi.x; in.l[5] = hi.y; in.l[6] = hi.z; in.l[7] = hi.w;
     }
     unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
-    const Fr out = lanes_perm(&d_lanes, L, in, st);
+    const Fr out = lanes_perm<false>(&d_lanes, L, in, st);
+    if (lane < 5) {
+        uint4 *q = reinterpret_cast<uint4 *>(state + lane * 32);
+        q[0] = make_uint4(out.l[0], out.l[1], out.l[2], out.l[3]);
+        q[1] = make_uint4(out.l[4], out.l[5], out.l[6], out.l[7]);
+    }
+    if (threadIdx.x == 0) {
+        stamps[0] = st[0] - t0;
+        stamps[1] = st[1] - st[0];
+        stamps[2] = __builtin_amdgcn_s_memtime() - st[1];
+        for (int i = 2; i < 6; i++) stamps[1 + i] = st[i];
+    }
+}
+
+// the helped form: wave 0 = the state's main wave (stamped), wave 3 = the helper, waves 1 and 2 idle
+__global__ void __launch_bounds__(256) k_perm_stamped_helped(uint8_t *state, unsigned long long *stamps) {
+    __shared__ LanesLds L[3];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 3) {
+        lanes_helper<3>(&d_lanes, L);
+        return;
+    }
+    if (wave != 0) {
+        lanes_idle();
+        return;
+    }
+    Fr in;
+    for (int i = 0; i < 8; i++) in.l[i] = 0;
+    if (lane < 5) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(state + lane * 32);
+        const uint4 lo = q[0], hi = q[1];
+        in.l[0] = lo.x; in.l[1] = lo.y; in.l[2] = lo.z; in.l[3] = lo.w;
+        in.l[4] = hi.x; in.l[5] = hi.y; in.l[6] = hi.z; in.l[7] = hi.w;
+    }
+    unsigned long long st[6] = {0, 0, 0, 0, 0, 0};
+    const Fr out = lanes_perm<true>(&d_lanes, L[0], in, st);
     if (lane < 5) {
         uint4 *q = reinterpret_cast<uint4 *>(state + lane * 32);
         q[0] = make_uint4(out.l[0], out.l[1], out.l[2], out.l[3]);
@@ -205,6 +241,15 @@ int main() {
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(h3, d_st3, 56, hipMemcpyDeviceToHost));
         printf("one permutation by one wave (stamped): input stage %llu cycles, 67 rounds %llu cycles (%.1f per round), output stage %llu cycles\n",
+               h3[0], h3[1], h3[1] / 67.0, h3[2]);
+        printf("   partial rounds: products + exchange %.1f, linear layer %.1f cycles per round;  full rounds: %.1f, %.1f\n",
+               h3[3] / 59.0, h3[4] / 59.0, h3[5] / 8.0, h3[6] / 8.0);
+    }
+    for (int rep = 0; rep < 3; rep++) {
+        hipLaunchKernelGGL(k_perm_stamped_helped, dim3(1), dim3(256), 0, 0, d_state, d_st3);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(h3, d_st3, 56, hipMemcpyDeviceToHost));
+        printf("with a helper wave for word 3 (stamped main wave): input stage %llu cycles, 67 rounds %llu cycles (%.1f per round), output stage %llu cycles\n",
                h3[0], h3[1], h3[1] / 67.0, h3[2]);
         printf("   partial rounds: products + exchange %.1f, linear layer %.1f cycles per round;  full rounds: %.1f, %.1f\n",
                h3[3] / 59.0, h3[4] / 59.0, h3[5] / 8.0, h3[6] / 8.0);
