@@ -72,6 +72,8 @@ SIGNATURES = {
                                              c_void_p]),
     "hades252_merkle_verify_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, POINTER(c_uint64), c_int,
                                            c_void_p, c_void_p]),
+    "hades252_merkle_update_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_int, POINTER(c_uint64), c_int, c_void_p,
+                                           c_void_p, c_size_t, c_void_p]),
     "hades252_merkle_forest_scratch_bytes": (c_size_t, [c_size_t, c_size_t, c_int]),
     "hades252_merkle_forest_dev": (c_int, [c_void_p, c_size_t, c_size_t, c_int, c_void_p, c_size_t, POINTER(c_uint64),
                                            c_int, c_void_p, c_void_p]),

@@ -506,23 +506,27 @@ __global__ void __launch_bounds__(kCoopThreads) k_perm_coop(uint8_t *states, siz
 //   plain    four states per block, every wave does everything itself: 54 us -- for 769 .. 1 024 states, where the helped
 //            form would put a second block on some CUs.
 constexpr int kLanesWaves = 4;
-template <bool HELPED>
-__device__ __forceinline__ bool lanes_role(LanesLds *L, size_t n, size_t &rec) {        // false: this wave is done
-    const int wave = threadIdx.x >> 6;
+struct LanesAlways {
+    __device__ __forceinline__ bool operator()(size_t) const { return true; }
+};
+// `wanted(rec)` (wave-uniform) lets a kernel drop records it does not need; such a wave idles like one past the end
+template <bool HELPED, class Wanted = LanesAlways>
+__device__ __forceinline__ bool lanes_role(LanesLds *L, size_t n, size_t &rec, Wanted wanted = Wanted()) {
+    const int wave = threadIdx.x >> 6;                                                   // false: this wave is done
     if constexpr (HELPED) {
         if (wave == kLanesWaves - 1) {
             lanes_helper<kLanesWaves - 1>(&d_lanes, *reinterpret_cast<LanesLds(*)[kLanesWaves - 1]>(L));
             return false;
         }
         rec = (size_t)blockIdx.x * (kLanesWaves - 1) + wave;
-        if (rec >= n) {
+        if (rec >= n || !wanted(rec)) {
             lanes_idle();
             return false;
         }
         return true;
     } else {
         rec = (size_t)blockIdx.x * kLanesWaves + wave;
-        return rec < n;                                              // no block-wide barrier anywhere: idle waves leave
+        return rec < n && wanted(rec);                               // no block-wide barrier anywhere: idle waves leave
     }
 }
 
@@ -557,6 +561,69 @@ __global__ void __launch_bounds__(kLanesWaves *kWave) k_merkle_lanes(const uint8
     }
     const Fr out = lanes_perm<HELPED>(&d_lanes, L[wave], in);
     if (lane == out_idx) store_word(parents + rec * 32, out);
+}
+
+// Incremental update, one level: query q names a changed LEAF indices[q]; its ancestor on this level is parent
+// p = indices[q] / span (span = ARITY^(level+1)), recomputed from the level below (already up to date) and written in
+// place.  A query whose predecessor has the same ancestor leaves it to the predecessor (sorted index lists do each
+// ancestor once; unsorted ones may repeat work, never miss any: the first query of every run computes it; concurrent
+// writers of one parent write identical bytes).  Leaf indices >= n_leaves are ignored.
+struct UpdateWanted {
+    const uint64_t *indices;
+    size_t n_leaves;
+    uint64_t span;
+    __device__ __forceinline__ bool operator()(size_t q) const {
+        const uint64_t i = indices[q];
+        if (i >= n_leaves) return false;
+        if (q == 0) return true;
+        const uint64_t j = indices[q - 1];
+        return j >= n_leaves || j / span != i / span;
+    }
+};
+
+template <int ARITY>
+__device__ __forceinline__ Fr update_child(const uint8_t *__restrict__ children, size_t n_children, size_t parent, int w,
+                                           const uint8_t *__restrict__ pad) {
+    const size_t c = parent * ARITY + w;
+    return c < n_children ? load_word(children + c * 32) : load_pad(pad);
+}
+
+template <int ARITY>
+__global__ void __launch_bounds__(kBlock, 4) k_merkle_update_fast(const uint8_t *__restrict__ children, size_t n_children,
+                                                                  uint8_t *__restrict__ parents,
+                                                                  const uint64_t *__restrict__ indices, size_t n_updates,
+                                                                  size_t n_leaves, uint64_t span, Fr tag, int out_idx,
+                                                                  const uint8_t *__restrict__ pad) {
+    const size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const UpdateWanted wanted{indices, n_leaves, span};
+    if (q >= n_updates || !wanted(q)) return;
+    const size_t parent = indices[q] / span;
+    Fr st[5];
+    st[0] = tag;
+#pragma unroll
+    for (int w = 1; w < 5; w++) st[w] = w <= ARITY ? update_child<ARITY>(children, n_children, parent, w - 1, pad) : zero_word();
+    Fr out[1];
+    fast_perm<1>(&d_fast, st, out, out_idx);
+    store_word(parents + parent * 32, out[0]);
+}
+
+template <int ARITY, bool HELPED>
+__global__ void __launch_bounds__(kLanesWaves *kWave) k_merkle_update_lanes(const uint8_t *__restrict__ children,
+                                                                            size_t n_children, uint8_t *__restrict__ parents,
+                                                                            const uint64_t *__restrict__ indices,
+                                                                            size_t n_updates, size_t n_leaves, uint64_t span,
+                                                                            Fr tag, int out_idx,
+                                                                            const uint8_t *__restrict__ pad) {
+    __shared__ LanesLds L[kLanesWaves];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    size_t q;
+    if (!lanes_role<HELPED>(L, n_updates, q, UpdateWanted{indices, n_leaves, span})) return;
+    const size_t parent = indices[q] / span;
+    Fr in = zero_word();
+    if (lane == 0) in = tag;
+    if (lane >= 1 && lane <= ARITY) in = update_child<ARITY>(children, n_children, parent, lane - 1, pad);
+    const Fr out = lanes_perm<HELPED>(&d_lanes, L[wave], in);
+    if (lane == out_idx) store_word(parents + parent * 32, out);
 }
 
 // Fused Merkle levels: block b takes the children of parents [64b, 64b + 64) of one level (n_parents in
@@ -1036,6 +1103,33 @@ static void launch_merkle_coop(int arity, const uint8_t *children, uint8_t *out_
         default: HADES_LAUNCH_COOP(4); break;
     }
 #undef HADES_LAUNCH_COOP
+}
+
+// the ancestors of n_updates changed leaves on one level (k_merkle_update_*): one per wave up to kLanesMaxStates queries
+static void launch_merkle_update(int arity, const uint8_t *children, size_t n_children, uint8_t *parents,
+                                 const uint64_t *indices, size_t n_updates, size_t n_leaves, uint64_t span, Fr tag,
+                                 int out_idx, const uint8_t *pad, hipStream_t s) {
+    const bool lanes = n_updates <= kLanesMaxStates, helped = n_updates <= kLanesHelpedMaxStates;
+    const unsigned per_block = helped ? kLanesWaves - 1 : kLanesWaves;
+    const dim3 grid((unsigned)((n_updates + per_block - 1) / per_block)), block(kLanesWaves * kWave);
+#define HADES_LAUNCH_UPDATE(A)                                                                                          \
+    do {                                                                                                                \
+        if (!lanes)                                                                                                     \
+            hipLaunchKernelGGL(k_merkle_update_fast<A>, dim3(blocks_for(n_updates)), dim3(kBlock), 0, s, children,     \
+                               n_children, parents, indices, n_updates, n_leaves, span, tag, out_idx, pad);             \
+        else if (helped)                                                                                                \
+            hipLaunchKernelGGL((k_merkle_update_lanes<A, true>), grid, block, 0, s, children, n_children, parents,     \
+                               indices, n_updates, n_leaves, span, tag, out_idx, pad);                                  \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_merkle_update_lanes<A, false>), grid, block, 0, s, children, n_children, parents,    \
+                               indices, n_updates, n_leaves, span, tag, out_idx, pad);                                  \
+    } while (0)
+    switch (arity) {
+        case 2: HADES_LAUNCH_UPDATE(2); break;
+        case 3: HADES_LAUNCH_UPDATE(3); break;
+        default: HADES_LAUNCH_UPDATE(4); break;
+    }
+#undef HADES_LAUNCH_UPDATE
 }
 
 // One level, the kernel chosen by size: `n_children` children -> ceil(n_children / arity) parents.
@@ -1837,7 +1931,7 @@ size_t hades252_merkle4_scratch_bytes(size_t n_leaves) { return hades252_merkle_
 // parent per lane (throughput); full levels of 1 025 .. 16 384 parents run five waves per parent, with arity 2 / 4 and a
 // power-of-arity level taking 64 parents per block through several levels inside the CU (k_merkle_coop) as long as
 // the next level is still that large; levels of at most kLanesMaxStates parents run one parent per wave
-// (k_merkle_lanes: ~59 us per level instead of ~104).  Ragged levels: a child position past the end of level l takes
+// (k_merkle_lanes: ~51 us per level instead of ~104).  Ragged levels: a child position past the end of level l takes
 // pad[l] (device table of depth digests, NULL = zeros).
 // tree != NULL: every level is kept (layout of hades252_merkle_build_dev); else ping-pong in buf_a / buf_b.
 static int merkle_run(const uint8_t *leaves, size_t n_leaves, int arity, uint8_t *tree, uint8_t *buf_a, uint8_t *buf_b,
@@ -1929,6 +2023,41 @@ int hades252_merkle_build_pad_dev(const void *d_leaves, size_t n_leaves, int ari
 int hades252_merkle_build_dev(const void *d_leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
                               void *d_tree, void *stream) {
     return hades252_merkle_build_pad_dev(d_leaves, n_leaves, arity, tag_mont, out_idx, nullptr, d_tree, stream);
+}
+
+// Incremental update: the caller has overwritten the leaves d_leaves[d_indices[q]], q < n_updates; their ancestors in
+// d_tree (built by hades252_merkle_build[_pad]_dev with the same parameters) are recomputed bottom-up, one launch per
+// level: depth x min(n_updates, n_level) permutations instead of the whole tree.  A level with no more parents than
+// updates is simply recomputed whole.
+int hades252_merkle_update_dev(const void *d_leaves, void *d_tree, size_t n_leaves, int arity, const uint64_t tag_mont[4],
+                               int out_idx, const void *d_pad, const uint64_t *d_indices, size_t n_updates, void *stream) {
+    const int depth = hades252_merkle_depth(n_leaves, arity);
+    if (depth < 1 || tag_mont == nullptr || out_idx < 0 || out_idx >= 5) return HADES252_ERR_INVALID_ARG;
+    if (n_updates == 0) return HADES252_OK;
+    if (d_leaves == nullptr || d_tree == nullptr || d_indices == nullptr || n_updates > kMaxLaunchRecords ||
+        misaligned(d_leaves) || misaligned(d_tree) || misaligned(d_pad))
+        return HADES252_ERR_INVALID_ARG;
+    const Fr tag = fr_from_u64(tag_mont);
+    hipStream_t s = (hipStream_t)stream;
+    const uint8_t *src = (const uint8_t *)d_leaves, *pad = (const uint8_t *)d_pad;
+    uint8_t *tree = (uint8_t *)d_tree;
+    size_t n = n_leaves, off = 0;
+    uint64_t span = 1;
+    for (int l = 0; l < depth; l++) {
+        const size_t parents = (n + arity - 1) / arity;
+        const uint8_t *pad_l = pad != nullptr ? pad + (size_t)l * 32 : nullptr;
+        uint8_t *dst = tree + off;
+        span *= (uint64_t)arity;
+        if (parents <= n_updates)
+            launch_merkle_any(arity, src, n, dst, tag, out_idx, pad_l, s);
+        else
+            launch_merkle_update(arity, src, n, dst, d_indices, n_updates, n_leaves, span, tag, out_idx, pad_l, s);
+        HIP_TRY(hipGetLastError());
+        off += parents * 32;
+        src = dst;
+        n = parents;
+    }
+    return HADES252_OK;
 }
 
 // pad[0] = e0 (the digest standing for a missing leaf), pad[l+1] = perm([tag, pad[l] x arity, 0 ..])[out_idx]: the

@@ -452,6 +452,23 @@ def merkle_verify(leaf_values_t, indices_t, paths_t, arity: int, tag_mont: int, 
     return roots
 
 
+def merkle_update(leaves_t, tree_t, arity: int, indices_t, tag_mont: int, out_idx: int = 1, pad=None):
+    """Re-hash, in place in ``tree_t``, the ancestors of the leaves named by ``indices_t`` (device int64/uint64) after the
+    caller has overwritten those rows of ``leaves_t``: depth x n_updates permutations instead of the whole tree."""
+    import torch
+    ptr, n, dev = _dev_buffer(leaves_t, 32, "merkle_update")
+    depth = merkle_depth(n, arity, "merkle_update")
+    tptr, nt, _ = _dev_buffer(tree_t, 32, "merkle_update")
+    if nt != sum(merkle_level_sizes(n, arity)):
+        raise ValueError("merkle_update: tree buffer does not belong to %d leaves" % n)
+    iptr, nq, _ = _dev_buffer(indices_t, 8, "merkle_update")
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_merkle_update_dev(ptr, tptr, n, arity, _tag_arr(tag_mont), out_idx,
+                                                    _pad_ptr(pad, depth, "merkle_update"), iptr, nq, _stream_ptr(dev)),
+              "merkle_update")
+    return tree_t
+
+
 def merkle_forest(leaves_t, n_trees: int, arity: int, tag_mont: int, out_idx: int = 1, scratch=None):
     """Roots of n_trees equal trees (leaves contiguous, tree after tree; leaves per tree a power of the arity)."""
     import torch

@@ -64,7 +64,8 @@ extern "C" {
                                      latency, ~2/3 of the throughput; DEFAULT picks it for 1024 < n_perms <= 16384 */
 #define HADES252_KERNEL_LANES 4   /* one state per wave, every field element spread over a 16-lane row (products by the
                                      row, lane-parallel carries): the lowest latency for ONE permutation -- the
-                                     reference's own call shape (README.md:60-61); DEFAULT picks it for n_perms <= 1024 */
+                                     reference's own call shape (README.md:60-61); DEFAULT picks it for n_perms <= 1024
+                                     (up to 768 with a helper wave per three states: 50 us) */
 
 /* ---- meta --------------------------------------------------------------------------- */
 /* Strategy::rounds() (src/strategies.rs:160-162): TOTAL_FULL_ROUNDS + PARTIAL_ROUNDS = 67 */
@@ -218,6 +219,14 @@ int hades252_merkle_open_pad_dev(const void *d_leaves, const void *d_tree, size_
  * trusts.  One query per lane, `depth` permutations each; arity 1 .. 4. */
 int hades252_merkle_verify_dev(const void *d_leaves, const uint64_t *d_indices, const void *d_paths, size_t n_queries,
                                int depth, int arity, const uint64_t tag_mont[4], int out_idx, void *d_roots, void *stream);
+/* Incremental update (the append / overwrite path of a Merkle-tree caller: README.md:9 names the tree, the update is the
+ * operation it serves): the caller has overwritten the leaves d_leaves[d_indices[q]], q < n_updates (device u64; sorted
+ * lists do each ancestor once, any order is correct, an index >= n_leaves is ignored); their ancestors in d_tree -- built
+ * by hades252_merkle_build[_pad]_dev with the same arity, tag, out_idx and pad -- are recomputed bottom-up in place:
+ * at most depth * n_updates permutations, one launch per level, one ancestor per wave for up to 1 024 updates (~51 us a
+ * level).  A level with no more parents than updates is recomputed whole. */
+int hades252_merkle_update_dev(const void *d_leaves, void *d_tree, size_t n_leaves, int arity, const uint64_t tag_mont[4],
+                               int out_idx, const void *d_pad, const uint64_t *d_indices, size_t n_updates, void *stream);
 /* Forest: n_trees independent trees of leaves_per_tree = arity^k leaves each (leaves contiguous, tree after tree); level l
  * of all trees is one launch; d_roots receives n_trees roots.  Scratch: hades252_merkle_forest_scratch_bytes. */
 size_t hades252_merkle_forest_scratch_bytes(size_t n_trees, size_t leaves_per_tree, int arity);

@@ -310,6 +310,48 @@ def test_merkle_verify_2pow16_queries(torch_cuda, H, oracle):
     assert (to_host(r1) == cur).all()
 
 
+@pytest.mark.parametrize("arity,n_leaves,n_updates", [(4, 4 ** 7 * 3, 1), (4, 4 ** 7 * 3, 300), (4, 100001, 800), (2, 2 ** 15 + 11, 1024),
+                                                      (3, 3 ** 9, 5000), (4, 4 ** 8 + 1, 20000), (2, 3, 2), (4, 5, 1)])
+def test_merkle_update_equals_rebuild(torch_cuda, H, oracle, arity, n_leaves, n_updates):
+    """Overwrite k leaves, re-hash their ancestors only: the tree equals the oracle's tree over the new leaves -- sorted and
+    shuffled index lists with repeats, out-of-range indices ignored, every kernel form (wave / helped wave / lane / whole level)."""
+    torch = torch_cuda
+    tag = TAG[arity]
+    depth = H.merkle_depth(n_leaves, arity)
+    e0 = S.to_mont(0xE0)
+    pad = H.merkle_empty_digests(arity, depth, e0, tag, 1)
+    opad = oracle.merkle_empty_digests(arity, depth, e0, tag, 1)
+    leaves = rows(oracle.gen_b(n_leaves + 1, n_leaves)).copy()
+    dl = to_dev(torch, leaves.reshape(-1)).view(-1, 4)
+    tree = H.merkle_build(dl, arity, tag, 1, pad=pad)
+    rng = random.Random(n_leaves * 31 + n_updates)
+    for order in ("sorted", "shuffled"):
+        idx = [rng.randrange(n_leaves) for _ in range(n_updates)]
+        idx[0] = n_leaves - 1                                  # the ragged end: its siblings are padding
+        if n_updates > 2:
+            idx[1] = idx[2]                                    # a repeat
+        idx = sorted(idx) if order == "sorted" else idx
+        fresh = rows(oracle.gen_b(rng.randrange(1 << 30), n_updates))
+        for q, i in enumerate(idx):
+            leaves[i] = fresh[q]
+        dl.copy_(to_dev(torch, leaves.reshape(-1)).view(-1, 4))
+        before = tree.clone()
+        with_bogus = idx + [n_leaves, 2 ** 63 - 1]             # ignored, never read or written
+        didx = torch.tensor(with_bogus, dtype=torch.int64, device="cuda")
+        H.merkle_update(dl, tree, arity, didx, tag, 1, pad=pad)
+        exp = np.concatenate(oracle.merkle_tree(leaves.reshape(-1), arity, tag, 1, opad))
+        assert (to_host(tree) == exp).all(), order
+        if n_updates * depth < sum(H.merkle_level_sizes(n_leaves, arity)) // 4:
+            assert int((tree != before).any(dim=1).sum().item()) <= n_updates * depth      # nothing else was touched
+    # no table = zero padding, and an empty update list is a no-op
+    t0 = H.merkle_build(dl, arity, tag, 1)
+    leaves[0] = rows(oracle.gen_b(77, 1))[0]
+    dl.copy_(to_dev(torch, leaves.reshape(-1)).view(-1, 4))
+    H.merkle_update(dl, t0, arity, torch.zeros(0, dtype=torch.int64, device="cuda"), tag, 1)
+    H.merkle_update(dl, t0, arity, torch.zeros(1, dtype=torch.int64, device="cuda"), tag, 1)
+    assert (to_host(t0) == np.concatenate(oracle.merkle_tree(leaves.reshape(-1), arity, tag, 1))).all()
+
+
 @pytest.mark.parametrize("arity,k,n_trees", [(4, 4, 10 ** 4), (4, 1, 1000), (2, 10, 333), (3, 5, 2000), (4, 6, 7)])
 def test_merkle_forest_vs_oracle(torch_cuda, H, oracle, arity, k, n_trees):
     torch = torch_cuda

@@ -64,7 +64,7 @@ def sec_merkle():
     for _ in range(7):
         ts.append(timed(lambda: H.merkle4_root(leaves, tag, 1, scratch), reps=3))
     print("leaves=2^24 root, 7 x 3 runs: min %.3f ms  median %.3f ms" % (min(ts) * 1e3, sorted(ts)[3] * 1e3))
-    dt = timed(lambda: H.merkle_build(leaves, 4, tag, 1), reps=3)
+    dt = dtb = timed(lambda: H.merkle_build(leaves, 4, tag, 1), reps=3)
     tree = H.merkle_build(leaves, 4, tag, 1)
     idx = torch.randint(0, n, (1 << 16,), dtype=torch.int64, device=dev)
     dto = timed(lambda: H.merkle_open(leaves, tree, 4, idx), reps=5)
@@ -75,6 +75,13 @@ def sec_merkle():
     dtv = timed(lambda: H.merkle_verify(lv, idx, pths, 4, tag, 1), reps=5)
     print("verify 2^16 openings of the 2^24-leaf tree (12 permutations each): %8.3f ms  %8.2f Mperm/s  all roots ok: %s"
           % (dtv * 1e3, 12 * (1 << 16) / dtv / 1e6, bool((roots == tree[-1:]).all())))
+    g = torch.Generator(device="cpu")
+    g.manual_seed(11)
+    for k_upd in (1, 256, 768, 1024, 1 << 14, 1 << 18):
+        ui = torch.sort(torch.randint(0, n, (k_upd,), generator=g, dtype=torch.int64))[0].to(dev)
+        dtu = timed(lambda: H.merkle_update(leaves, tree, 4, ui, tag, 1), reps=5)
+        print("update %7d leaves of the 2^24-leaf tree (their 12 ancestors each, sorted indices): %8.3f ms  (full rebuild %.1f ms)"
+              % (k_upd, dtu * 1e3, dtb * 1e3))
     del tree, leaves, pths, lv
     for nt, k in ((4096, 4), (10 ** 4, 4), (1 << 16, 2)):
         per = 4 ** k
