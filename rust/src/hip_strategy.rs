@@ -98,9 +98,9 @@ pub struct HipStrategy {
     /// 0 = current device only; n > 0 = shard host batches over the first n GPUs.
     pub devices: i32,
     /// Batches of fewer permutations than this stay on the reference's own `ScalarStrategy`
-    /// (0 = always use the GPU).  Measured on MI355X: one GPU call costs ~121 us whatever the batch
-    /// size up to 16384 states, one CPU permutation ~30-60 us; 3 is the break-even for a
-    /// single-threaded caller.  (libhades252 itself has no CPU path.)
+    /// (0 = always use the GPU, the default).  Measured on MI355X: one GPU call costs ~65 us for up to
+    /// 768 states (50 us of it the kernel), one CPU permutation ~52 us: the GPU wins from two states
+    /// on.  (libhades252 itself has no CPU path.)
     pub cpu_below: usize,
 }
 
