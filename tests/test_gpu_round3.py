@@ -352,6 +352,24 @@ def test_merkle_update_equals_rebuild(torch_cuda, H, oracle, arity, n_leaves, n_
     assert (to_host(t0) == np.concatenate(oracle.merkle_tree(leaves.reshape(-1), arity, tag, 1))).all()
 
 
+def test_merkle_update_at_baseline_size(torch_cuda, H):
+    """BASELINE configs[3] (arity 4, 2^24 leaves): k updated leaves, then the whole tree equals a fresh build (the build
+    itself is checked against the oracle by decomposition in test_gpu_round2) -- k on both sides of every kernel choice."""
+    torch = torch_cuda
+    n, tag = 1 << 24, TAG[4]
+    leaves = H.gen_b(n, "cuda")
+    tree = H.merkle_build(leaves, 4, tag, 1)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(2024)
+    for k in (1, 700, 1000, 3000, 1 << 17):
+        idx = torch.randint(0, n, (k,), generator=g, dtype=torch.int64).cuda()
+        if k > 1:
+            idx = idx[torch.randperm(k, generator=g).cuda()] if k == 3000 else torch.sort(idx)[0]
+        leaves[idx] = H.gen_b(k, "cuda", first_elem=(1 << 40) + 7 * k)
+        H.merkle_update(leaves, tree, 4, idx, tag, 1)
+        assert bool((tree == H.merkle_build(leaves, 4, tag, 1)).all()), k
+
+
 @pytest.mark.parametrize("arity,k,n_trees", [(4, 4, 10 ** 4), (4, 1, 1000), (2, 10, 333), (3, 5, 2000), (4, 6, 7)])
 def test_merkle_forest_vs_oracle(torch_cuda, H, oracle, arity, k, n_trees):
     torch = torch_cuda

@@ -196,15 +196,21 @@ int main() {
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(ha.data(), d_a, n * 32, hipMemcpyDeviceToHost));
         CK(hipMemcpy(hb.data(), d_b, n * 32, hipMemcpyDeviceToHost));
-        int bad = 0, first = -1;
-        for (int i = 0; i < n; i++)
+        // The signed per-lane S-box (sbox29) is specified for limbs up to 2^29 + small: with every limb at 2^30 + 1 its
+        // columns overflow, so those patterns (kinds 2, 3) are compared for the single product only; the lane S-box at
+        // its own operand maxima is checked limb by limb by tests/test_fast_model.py.
+        int bad = 0, first = -1, compared = 0;
+        for (int i = 0; i < n; i++) {
+            if (mode == 1 && (i % 8 == 2 || i % 8 == 3)) continue;
+            compared++;
             for (int j = 0; j < 8; j++)
                 if (ha[i * 8 + j] != hb[i * 8 + j]) {
                     bad++;
                     if (first < 0) first = i;
                     break;
                 }
-        printf("%s: %d pairs, %d mismatches%s\n", mode ? "lane S-box vs sbox29" : "lane product vs mont_fips", n, bad,
+        }
+        printf("%s: %d pairs, %d mismatches%s\n", mode ? "lane S-box vs sbox29" : "lane product vs mont_fips", compared, bad,
                bad ? "  <-- FAIL" : "  (bit-identical after full reduction)");
         if (bad) printf("  first mismatch: pair %d (kind %d)\n", first, first % 8);
     }
