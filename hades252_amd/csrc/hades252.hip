@@ -762,6 +762,15 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+__device__ __forceinline__ Fr one_mont_word() {                    // 1 * 2^256 mod p
+    const uint32_t r1[8] = {0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau,
+                            0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u};
+    Fr one;
+#pragma unroll
+    for (int i = 0; i < 8; i++) one.l[i] = r1[i];
+    return one;
+}
+
 __global__ void __launch_bounds__(kBlock, 3) k_sponge(const uint8_t *__restrict__ scalars,
                                                       const uint64_t *__restrict__ offsets,
                                                       const uint64_t *__restrict__ lengths,
@@ -796,13 +805,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_sponge(const uint8_t *__restrict_
         mx = other > mx ? other : mx;
     }
 
-    Fr one_mont;                               // 1 * 2^256 mod p
-    {
-        const uint32_t r1[8] = {0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau,
-                                0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u};
-#pragma unroll
-        for (int i = 0; i < 8; i++) one_mont.l[i] = r1[i];
-    }
+    const Fr one_mont = one_mont_word();
     Fr st[5];
     st[0] = capacity;
 #pragma unroll
@@ -846,6 +849,166 @@ __global__ void __launch_bounds__(kBlock, 3) k_sponge(const uint8_t *__restrict_
     }
     slab_put<1>(slab, 0, dig);
     slab_flush<1>(digests, rec0, n_msgs, slab);
+}
+
+// ---- small batches: one message / state / query per WAVE (hades_lanes.hpp) ---------------------------------------
+// The sponge is a chain of dependent permutations per message, so a batch of a few messages (the extreme: ONE long
+// message) is pure latency: ~51 us per block here instead of ~175 us with one message per lane.  Same two forms as
+// k_perm_lanes.  The helped form needs the same number of permutations from every wave of a block: all run to the
+// block's maximum block count and latch their digest after their own last block (as the lanes of a wave do in k_sponge).
+struct SpongeGeom {
+    uint64_t off, len, blocks;
+    bool bad;
+};
+__device__ __forceinline__ SpongeGeom sponge_geom(const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ lengths,
+                                                  size_t me, size_t fixed_len, size_t n_scalars, int pad_mode) {
+    SpongeGeom g;
+    g.off = offsets != nullptr ? offsets[me] : (uint64_t)me * fixed_len;
+    g.len = lengths != nullptr ? lengths[me] : (uint64_t)fixed_len;
+    g.bad = g.off > n_scalars || g.len > n_scalars - g.off;          // not inside the pool: never read, hashed as empty
+    if (g.bad) g.len = 0;
+    g.blocks = (g.len + (pad_mode == 1 ? 1 : 0) + 3) / 4;
+    if (g.blocks == 0) g.blocks = 1;
+    return g;
+}
+
+template <bool HELPED>
+__global__ void __launch_bounds__(kLanesWaves *kWave) k_sponge_lanes(const uint8_t *__restrict__ scalars,
+                                                                     const uint64_t *__restrict__ offsets,
+                                                                     const uint64_t *__restrict__ lengths,
+                                                                     uint8_t *__restrict__ digests, size_t n_msgs,
+                                                                     size_t fixed_len, Fr capacity, int pad_mode,
+                                                                     size_t n_scalars, int *bad_count) {
+    __shared__ LanesLds L[kLanesWaves];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    constexpr int kPer = HELPED ? kLanesWaves - 1 : kLanesWaves;
+    const size_t me = (size_t)blockIdx.x * kPer + wave;
+    uint64_t trips = 0;
+    if constexpr (HELPED) {
+#pragma unroll
+        for (int s = 0; s < kPer; s++) {
+            const size_t m = (size_t)blockIdx.x * kPer + s;
+            if (m < n_msgs) {
+                const uint64_t b = sponge_geom(offsets, lengths, m, fixed_len, n_scalars, pad_mode).blocks;
+                trips = b > trips ? b : trips;
+            }
+        }
+        if (wave == kPer) {
+            for (uint64_t t = 0; t < trips; t++)
+                lanes_helper<kPer>(&d_lanes, *reinterpret_cast<LanesLds(*)[kPer]>(L));
+            return;
+        }
+        if (me >= n_msgs) {
+            for (uint64_t t = 0; t < trips; t++) lanes_idle();
+            return;
+        }
+    } else {
+        if (me >= n_msgs) return;
+    }
+    const SpongeGeom g = sponge_geom(offsets, lengths, me, fixed_len, n_scalars, pad_mode);
+    if constexpr (!HELPED) trips = g.blocks;
+    if (g.bad && lane == 0 && bad_count != nullptr) atomicAdd(bad_count, 1);
+    const Fr one_mont = one_mont_word();
+    auto block_word = [&](uint64_t t) {                              // lane 1 + k: scalar 4t + k of the message
+        Fr v = zero_word();
+        if (lane >= 1 && lane <= 4) {
+            const uint64_t idx = 4 * t + (uint64_t)(lane - 1);
+            if (idx < g.len)
+                v = load_word(scalars + (g.off + idx) * 32);
+            else if (pad_mode == 1 && idx == g.len)
+                v = one_mont;
+        }
+        return v;
+    };
+    Fr st = lane == 0 ? capacity : zero_word();
+    Fr dig = zero_word(), nxt = block_word(0);
+#pragma unroll 1
+    for (uint64_t t = 0; t < trips; t++) {
+        if (lane >= 1 && lane <= 4) st = fr_add(st, nxt);
+        nxt = block_word(t + 1);                                     // in flight during the permutation
+        st = lanes_perm<HELPED>(&d_lanes, L[wave], st);
+        if (t + 1 == g.blocks) dig = st;
+    }
+    if (lane == 1) store_word(digests + me * 32, dig);
+}
+
+// streaming absorb, one state per wave
+template <bool HELPED>
+__global__ void __launch_bounds__(kLanesWaves *kWave) k_sponge_absorb_lanes(uint8_t *states, const uint8_t *__restrict__ blocks,
+                                                                            size_t n, int blocks_each) {
+    __shared__ LanesLds L[kLanesWaves];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    constexpr int kPer = HELPED ? kLanesWaves - 1 : kLanesWaves;
+    const size_t me = (size_t)blockIdx.x * kPer + wave;
+    if constexpr (HELPED) {
+        if (wave == kPer) {
+            for (int t = 0; t < blocks_each; t++) lanes_helper<kPer>(&d_lanes, *reinterpret_cast<LanesLds(*)[kPer]>(L));
+            return;
+        }
+        if (me >= n) {
+            for (int t = 0; t < blocks_each; t++) lanes_idle();
+            return;
+        }
+    } else {
+        if (me >= n) return;
+    }
+    uint8_t *mine = states + me * 160 + (lane < 5 ? lane : 0) * 32;
+    const uint8_t *blk = blocks + me * (size_t)blocks_each * 128 + (lane >= 1 && lane <= 4 ? lane - 1 : 0) * 32;
+    Fr st = lane < 5 ? load_word(mine) : zero_word();
+    Fr nxt = load_word(blk);
+#pragma unroll 1
+    for (int t = 0; t < blocks_each; t++) {
+        if (lane >= 1 && lane <= 4) st = fr_add(st, nxt);
+        if (t + 1 < blocks_each) nxt = load_word(blk + (size_t)(t + 1) * 128);
+        st = lanes_perm<HELPED>(&d_lanes, L[wave], st);
+    }
+    if (lane < 5) store_word(mine, st);
+}
+
+// path verification, one query per wave: `depth` dependent permutations
+template <int ARITY, bool HELPED>
+__global__ void __launch_bounds__(kLanesWaves *kWave) k_merkle_verify_lanes(const uint8_t *__restrict__ leaves,
+                                                                            const uint64_t *__restrict__ indices,
+                                                                            const uint8_t *__restrict__ paths,
+                                                                            size_t n_queries, int depth, Fr tag, int out_idx,
+                                                                            uint8_t *__restrict__ roots) {
+    __shared__ LanesLds L[kLanesWaves];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    constexpr int kPer = HELPED ? kLanesWaves - 1 : kLanesWaves;
+    const size_t q = (size_t)blockIdx.x * kPer + wave;
+    if constexpr (HELPED) {
+        if (wave == kPer) {
+            for (int l = 0; l < depth; l++) lanes_helper<kPer>(&d_lanes, *reinterpret_cast<LanesLds(*)[kPer]>(L));
+            return;
+        }
+        if (q >= n_queries) {
+            for (int l = 0; l < depth; l++) lanes_idle();
+            return;
+        }
+    } else {
+        if (q >= n_queries) return;
+    }
+    uint64_t idx = indices[q];
+    const uint8_t *mine = paths + q * (size_t)depth * (ARITY - 1) * 32;
+    Fr node = load_word(leaves + q * 32);                            // every lane holds the path node
+    auto sibling = [&](int l, uint64_t at) {                         // lane 1 + c: child c of level l, unless it is the node
+        Fr v = zero_word();
+        const int pos = (int)(at % ARITY), c = lane - 1;
+        if (lane >= 1 && lane <= ARITY && c != pos) v = load_word(mine + ((size_t)l * (ARITY - 1) + (c < pos ? c : c - 1)) * 32);
+        return v;
+    };
+    Fr sib = sibling(0, idx);
+#pragma unroll 1
+    for (int l = 0; l < depth; l++) {
+        const int pos = (int)(idx % ARITY);
+        idx /= ARITY;
+        Fr in = lane == 0 ? tag : (lane == pos + 1 ? node : sib);
+        if (l + 1 < depth) sib = sibling(l + 1, idx);                // in flight during the permutation
+        const Fr out = lanes_perm<HELPED>(&d_lanes, L[wave], in);
+#pragma unroll
+        for (int i = 0; i < 8; i++) node.l[i] = __builtin_amdgcn_readlane(out.l[i], out_idx);
+    }
+    if (lane == 0) store_word(roots + q * 32, node);
 }
 
 // ---- ragged batches: counting sort of the message indices by block count --------------------------------
@@ -1815,6 +1978,21 @@ int hades252_merkle4_level_dev(const void *d_children, void *d_parents, size_t n
 static int sponge_launch(const void *d_scalars, const uint64_t *d_offsets, const uint64_t *d_lengths, size_t n_msgs,
                          size_t fixed_len, const uint64_t capacity_mont[4], int pad_mode, void *d_digests, void *stream,
                          size_t n_scalars, int *d_bad_count, const uint32_t *d_order) {
+    if (n_msgs <= kLanesMaxStates) {                    // a few messages: one per wave (any `order` is irrelevant there)
+        const bool helped = n_msgs <= kLanesHelpedMaxStates;
+        const unsigned per = helped ? kLanesWaves - 1 : kLanesWaves;
+        const dim3 grid((unsigned)((n_msgs + per - 1) / per)), block(kLanesWaves * kWave);
+        if (helped)
+            hipLaunchKernelGGL(k_sponge_lanes<true>, grid, block, 0, (hipStream_t)stream, (const uint8_t *)d_scalars,
+                               d_offsets, d_lengths, (uint8_t *)d_digests, n_msgs, fixed_len, fr_from_u64(capacity_mont),
+                               pad_mode, n_scalars, d_bad_count);
+        else
+            hipLaunchKernelGGL(k_sponge_lanes<false>, grid, block, 0, (hipStream_t)stream, (const uint8_t *)d_scalars,
+                               d_offsets, d_lengths, (uint8_t *)d_digests, n_msgs, fixed_len, fr_from_u64(capacity_mont),
+                               pad_mode, n_scalars, d_bad_count);
+        HIP_TRY(hipGetLastError());
+        return HADES252_OK;
+    }
     hipLaunchKernelGGL(k_sponge, dim3(blocks_for(n_msgs)), dim3(kBlock), lds_for(4), (hipStream_t)stream,
                        (const uint8_t *)d_scalars, d_offsets, d_lengths, (uint8_t *)d_digests, n_msgs, fixed_len,
                        fr_from_u64(capacity_mont), pad_mode, n_scalars, d_bad_count, d_order);
@@ -1851,6 +2029,8 @@ int hades252_sponge_hash_var_ex_dev(const void *d_scalars, size_t n_scalars, con
     if (d_scratch != nullptr) {
         if (scratch_bytes < hades252_sponge_sort_scratch_bytes(n_msgs)) return HADES252_ERR_SCRATCH;
         if (misaligned(d_scratch)) return HADES252_ERR_INVALID_ARG;
+    }
+    if (d_scratch != nullptr && n_msgs > kLanesMaxStates) {          // (one message per wave needs no sorting)
         hipStream_t s = (hipStream_t)stream;
         uint32_t *counters = (uint32_t *)d_scratch, *ord = counters + kSpongeBuckets + 4;
         HIP_TRY(hipMemsetAsync(counters, 0, (size_t)kSpongeBuckets * 4, s));
@@ -1890,6 +2070,19 @@ int hades252_sponge_absorb_dev(void *d_states, const void *d_blocks, size_t n_st
     if (d_states == nullptr || d_blocks == nullptr || n_states > kMaxLaunchRecords || misaligned(d_states) ||
         misaligned(d_blocks))
         return HADES252_ERR_INVALID_ARG;
+    if (n_states <= kLanesMaxStates) {
+        const bool helped = n_states <= kLanesHelpedMaxStates;
+        const unsigned per = helped ? kLanesWaves - 1 : kLanesWaves;
+        const dim3 grid((unsigned)((n_states + per - 1) / per)), block(kLanesWaves * kWave);
+        if (helped)
+            hipLaunchKernelGGL(k_sponge_absorb_lanes<true>, grid, block, 0, (hipStream_t)stream, (uint8_t *)d_states,
+                               (const uint8_t *)d_blocks, n_states, blocks_each);
+        else
+            hipLaunchKernelGGL(k_sponge_absorb_lanes<false>, grid, block, 0, (hipStream_t)stream, (uint8_t *)d_states,
+                               (const uint8_t *)d_blocks, n_states, blocks_each);
+        HIP_TRY(hipGetLastError());
+        return HADES252_OK;
+    }
     hipLaunchKernelGGL(k_sponge_absorb, dim3(blocks_for(n_states)), dim3(kBlock), lds_for(5), (hipStream_t)stream,
                        (uint8_t *)d_states, (const uint8_t *)d_blocks, n_states, blocks_each);
     HIP_TRY(hipGetLastError());
@@ -2120,10 +2313,23 @@ int hades252_merkle_verify_dev(const void *d_leaves, const uint64_t *d_indices, 
         n_queries > kMaxLaunchRecords || misaligned(d_leaves) || misaligned(d_paths) || misaligned(d_roots))
         return HADES252_ERR_INVALID_ARG;
     const Fr tag = fr_from_u64(tag_mont);
+    const bool lanes = n_queries <= kLanesMaxStates, helped = n_queries <= kLanesHelpedMaxStates;
+    const unsigned per = helped ? kLanesWaves - 1 : kLanesWaves;
+    const dim3 lgrid((unsigned)((n_queries + per - 1) / per)), lblock(kLanesWaves * kWave);
+#define HADES_VERIFY_ARGS                                                                                            \
+    (const uint8_t *)d_leaves, d_indices, (const uint8_t *)d_paths, n_queries, depth, tag, out_idx, (uint8_t *)d_roots
 #define HADES_LAUNCH_VERIFY(A)                                                                                       \
-    hipLaunchKernelGGL(k_merkle_verify<A>, dim3(blocks_for(n_queries)), dim3(kBlock), lds_for(1), (hipStream_t)stream, \
-                       (const uint8_t *)d_leaves, d_indices, (const uint8_t *)d_paths, n_queries, depth, tag, out_idx,   \
-                       (uint8_t *)d_roots)
+    do {                                                                                                             \
+        if (!lanes)                                                                                                  \
+            hipLaunchKernelGGL(k_merkle_verify<A>, dim3(blocks_for(n_queries)), dim3(kBlock), lds_for(1),           \
+                               (hipStream_t)stream, HADES_VERIFY_ARGS);                                              \
+        else if (helped)                                                                                             \
+            hipLaunchKernelGGL((k_merkle_verify_lanes<A, true>), lgrid, lblock, 0, (hipStream_t)stream,             \
+                               HADES_VERIFY_ARGS);                                                                   \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_merkle_verify_lanes<A, false>), lgrid, lblock, 0, (hipStream_t)stream,            \
+                               HADES_VERIFY_ARGS);                                                                   \
+    } while (0)
     switch (arity) {
         case 1: HADES_LAUNCH_VERIFY(1); break;
         case 2: HADES_LAUNCH_VERIFY(2); break;
@@ -2131,6 +2337,7 @@ int hades252_merkle_verify_dev(const void *d_leaves, const uint64_t *d_indices, 
         default: HADES_LAUNCH_VERIFY(4); break;
     }
 #undef HADES_LAUNCH_VERIFY
+#undef HADES_VERIFY_ARGS
     HIP_TRY(hipGetLastError());
     return HADES252_OK;
 }

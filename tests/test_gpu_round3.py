@@ -468,3 +468,108 @@ def test_streaming_sponge_absorb_squeeze(torch_cuda, H, oracle):
         assert (to_host(d.squeeze(w)).reshape(7, 4) == to_host(d.states).reshape(7, 5, 4)[:, w]).all()
     # the C ABI equivalence promised in the header: pad_mode 0 one-shot == streaming
     assert (to_host(H.sponge_hash(to_dev(torch, msgs).view(-1, 4), 4 * t, CAP, 0)) == exp).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# small batches: one message / state / query per wave (the low-latency forms of sponge, absorb and verification)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pad", [0, 1])
+def test_small_batch_sponge_one_message_per_wave(torch_cuda, hades_lib, H, oracle, pad):
+    """Batches on both sides of the two dispatch thresholds (768: helper wave, 1024: one message per lane), ragged lengths
+    inside a block of three / four waves (the helped form runs every wave to the block's maximum), empty messages,
+    overlapping messages, one LONG message alone, a message outside the pool."""
+    torch = torch_cuda
+    rng = random.Random(5 + pad)
+    pool = oracle.gen_b(1234, 3000)
+    dp = to_dev(torch, pool).view(-1, 4)
+    for n in (1, 2, 3, 4, 5, 100, 767, 768, 769, 1023, 1024, 1025):
+        lens = [rng.choice([0, 1, 2, 3, 4, 5, 7, 8, 9, 13, 40]) for _ in range(n)]
+        offs = [rng.randrange(0, 3000 - l + 1) for l in lens]              # anywhere in the pool: messages overlap
+        la, oa = np.array(lens, dtype=np.uint64), np.array(offs, dtype=np.uint64)
+        exp = oracle.sponge_var(pool, oa, la, CAP, pad)
+        got = to_host(H.sponge_hash_var(dp, to_dev(torch, oa), to_dev(torch, la), CAP, pad))
+        assert (got == exp).all(), n
+        if n in (3, 768, 1024):
+            assert (to_host(H.sponge_hash_var(dp, to_dev(torch, oa), to_dev(torch, la), CAP, pad, sort=True)) == exp).all()
+    # one long message (750 blocks): the chain of dependent permutations the low-latency form is for
+    one = oracle.sponge_var(pool, np.array([0], dtype=np.uint64), np.array([2999], dtype=np.uint64), CAP, pad)
+    assert (to_host(H.sponge_hash_var(dp, to_dev(torch, np.array([0], dtype=np.uint64)),
+                                      to_dev(torch, np.array([2999], dtype=np.uint64)), CAP, pad)) == one).all()
+    # fixed length, few messages
+    for n, ln in ((1, 9), (7, 4), (770, 3), (1024, 1)):
+        msgs = oracle.gen_b(n + ln, n * ln)
+        e = oracle.sponge(msgs, ln, CAP, pad)
+        assert (to_host(H.sponge_hash(to_dev(torch, msgs).view(-1, 4), ln, CAP, pad)) == e).all(), (n, ln)
+    # a message that does not lie inside the pool is hashed as the empty message and counted, never read
+    la = np.array([4, 8, 4, 3000], dtype=np.uint64)
+    oa = np.array([0, 2995, 3001, 1], dtype=np.uint64)                     # #1 runs past the end, #2 starts past it, #3 too long
+    bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out = torch.zeros((4, 4), dtype=torch.int64, device="cuda")
+    cap = (ctypes.c_uint64 * 4)(*limbs_of(CAP))
+    assert hades_lib.hades252_sponge_hash_var_dev(dp.data_ptr(), 3000, to_dev(torch, oa).data_ptr(),
+                                                  to_dev(torch, la).data_ptr(), 4, cap, pad, out.data_ptr(),
+                                                  bad.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    empty = oracle.sponge_var(pool, np.array([0], dtype=np.uint64), np.array([0], dtype=np.uint64), CAP, pad)
+    good = oracle.sponge_var(pool, oa[:1], la[:1], CAP, pad)
+    got = to_host(out).reshape(4, 4)
+    assert int(bad.item()) == 3 and (got[0] == good).all() and all((got[i] == empty).all() for i in (1, 2, 3))
+
+
+def test_small_batch_streaming_absorb(torch_cuda, H, oracle):
+    torch = torch_cuda
+    for n, t in ((1, 1), (1, 40), (3, 2), (4, 3), (767, 2), (769, 2), (1024, 1), (1025, 1)):
+        msgs = oracle.gen_b(31 * n + t, n * t * 4)
+        exp = oracle.sponge(msgs, 4 * t, CAP, 0)
+        st = H.SpongeStates(n, CAP)
+        st.absorb(to_dev(torch, msgs).view(n, t, 4, 4))
+        assert (to_host(st.squeeze()) == exp).all(), (n, t)
+        # the whole state equals the per-lane kernel's (forced by a batch above the threshold sharing the first n states)
+        if n <= 4:
+            big = H.SpongeStates(2000, CAP)
+            blocks = torch.zeros((2000, t, 4, 4), dtype=torch.int64, device="cuda")
+            blocks[:n] = to_dev(torch, msgs).view(n, t, 4, 4)
+            big.absorb(blocks)
+            assert torch.equal(big.states[:n], st.states)
+
+
+@pytest.mark.parametrize("arity", [1, 2, 3, 4])
+def test_small_batch_verify_one_query_per_wave(torch_cuda, H, oracle, arity):
+    """The same openings verified one per wave (<= 1024 queries, both forms) and one per lane (> 1024) give the same roots;
+    tampered siblings are caught."""
+    torch = torch_cuda
+    tag = TAG[arity]
+    if arity == 1:
+        chain = H.gen_b(1100, "cuda")
+        z = torch.zeros(1100, dtype=torch.int64, device="cuda")
+        e = torch.zeros((1100, 6, 0, 4), dtype=torch.int64, device="cuda")
+        ref = H.merkle_verify(chain, z, e, 1, tag, 1)
+        for m in (1, 3, 768, 769, 1024):
+            assert torch.equal(H.merkle_verify(chain[:m].contiguous(), z[:m].contiguous(), e[:m].contiguous(), 1, tag, 1), ref[:m])
+        return
+    n_leaves = arity ** 7 + 5
+    depth = H.merkle_depth(n_leaves, arity)
+    pad = H.merkle_empty_digests(arity, depth, S.to_mont(3), tag, 1)
+    leaves = H.gen_b(n_leaves, "cuda")
+    tree = H.merkle_build(leaves, arity, tag, 1, pad=pad)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(arity)
+    idx = torch.randint(0, n_leaves, (1100,), generator=g, dtype=torch.int64).cuda()
+    idx[0], idx[1] = n_leaves - 1, 0
+    paths = H.merkle_open(leaves, tree, arity, idx, pad=pad)
+    lv = leaves[idx].contiguous()
+    ref = H.merkle_verify(lv, idx, paths, arity, tag, 1)                      # 1100 queries: one per lane
+    assert bool((ref == tree[-1:]).all())
+    for m in (1, 2, 3, 4, 767, 768, 769, 1024):
+        r = H.merkle_verify(lv[:m].contiguous(), idx[:m].contiguous(), paths[:m].contiguous(), arity, tag, 1)
+        assert torch.equal(r, ref[:m]), m
+    bad = paths[:5].clone()
+    bad[2, depth // 2, 0, 1] ^= 4
+    r = H.merkle_verify(lv[:5].contiguous(), idx[:5].contiguous(), bad, arity, tag, 1)
+    assert not torch.equal(r[2], ref[2]) and torch.equal(r[:2], ref[:2]) and torch.equal(r[3:], ref[3:5])
+    # out_idx other than 1, against the oracle's path walk
+    hp = to_host(paths[:3]).reshape(3, depth, arity - 1, 4)
+    r3 = to_host(H.merkle_verify(lv[:3].contiguous(), idx[:3].contiguous(), paths[:3].contiguous(), arity, tag, 3)).reshape(3, 4)
+    hl = to_host(lv[:3]).reshape(3, 4)
+    for q in range(3):
+        assert (oracle.merkle_verify_path(hl[q], int(idx[q].item()), hp[q], arity, tag, 3) == r3[q]).all()

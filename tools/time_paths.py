@@ -280,8 +280,34 @@ def sec_sponge_var():
     print("streaming absorb, 2^22 states x 1 block: %8.3f ms  %8.2f Mperm/s" % (dt * 1e3, (1 << 22) / dt / 1e6))
 
 
+def sec_small():
+    print("== small batches of dependent-permutation work: one message / state / query per wave (<= 1024) vs one per lane")
+    pool = H.gen_b(4 * 4096 + 8, dev)
+    for nmsg, blocks in ((1, 1000), (1, 100), (64, 100), (768, 100), (1024, 100), (1025, 100), (4096, 100)):
+        ln = 4 * blocks - 1                                           # + the padding 1 = `blocks` blocks exactly
+        offs = (torch.arange(nmsg, dtype=torch.int64) % 7).to(dev)
+        lens = torch.full((nmsg,), ln, dtype=torch.int64, device=dev)
+        dt = timed(lambda: H.sponge_hash_var(pool, offs, lens, cap, 1), reps=3)
+        print("sponge: %5d message(s) x %4d blocks: %9.3f ms = %7.1f us per block  (%s)"
+              % (nmsg, blocks, dt * 1e3, dt * 1e6 / blocks, "one message per wave" if nmsg <= 1024 else "one message per lane"))
+    for n in (1, 768, 1024, 1025):
+        st = H.SpongeStates(n, cap)
+        blk = H.gen_b(n * 50 * 4, dev).view(n, 50, 4, 4)
+        dt = timed(lambda: st.absorb(blk), reps=3)
+        print("streaming absorb: %5d state(s) x 50 blocks: %9.3f ms = %7.1f us per block" % (n, dt * 1e3, dt * 1e6 / 50))
+    n = 1 << 24
+    leaves = H.gen_b(n, dev)
+    tree = H.merkle_build(leaves, 4, tag, 1)
+    for nq in (1, 64, 768, 1024, 1025, 1 << 16):
+        idx = torch.randint(0, n, (nq,), dtype=torch.int64, device=dev)
+        pths = H.merkle_open(leaves, tree, 4, idx)
+        lv = leaves[idx].contiguous()
+        dt = timed(lambda: H.merkle_verify(lv, idx, pths, 4, tag, 1), reps=5)
+        print("verify %6d opening(s) of the 2^24-leaf tree (12 dependent permutations each): %9.3f ms" % (nq, dt * 1e3))
+
+
 if __name__ == "__main__":
-    want = sys.argv[1:] or ['device', 'host_small', 'merkle', 'host', 'latency', 'wire', 'perop', 'sponge', 'sponge_var']
+    want = sys.argv[1:] or ['device', 'host_small', 'merkle', 'host', 'latency', 'wire', 'perop', 'sponge', 'sponge_var', 'small']
     for nm in want:
         globals()["sec_" + nm]()
         torch.cuda.empty_cache()
