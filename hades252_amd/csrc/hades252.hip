@@ -1011,6 +1011,153 @@ __global__ void __launch_bounds__(kLanesWaves *kWave) k_merkle_verify_lanes(cons
     if (lane == 0) store_word(roots + q * 32, node);
 }
 
+// ---- mid-size batches (up to kCoopMaxStates): five waves per message / state / query (hades_coop.hpp) ------------
+// Same chains on the five-waves arithmetic: ~106 us per dependent permutation instead of ~160 with one per lane.  A block
+// holds 64 chains (lane = chain, wave = state word); every wave runs the block's maximum trip count (coop_rounds
+// contains block barriers) and the results are latched per lane.
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint64_t other = shfl_u64(v, lane ^ o);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(kCoopThreads) k_sponge_coop(const uint8_t *__restrict__ scalars,
+                                                             const uint64_t *__restrict__ offsets,
+                                                             const uint64_t *__restrict__ lengths,
+                                                             uint8_t *__restrict__ digests, size_t n_msgs, size_t fixed_len,
+                                                             Fr capacity, int pad_mode, size_t n_scalars, int *bad_count) {
+    __shared__ CoopLds L;
+    const int wv = coop_word_of_wave(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));   // the word this wave owns
+    const int lane = threadIdx.x & (kWave - 1);
+    const size_t me = (size_t)blockIdx.x * kCoopStates + lane;
+    const bool live = me < n_msgs;
+    coop_load_constants(&d_coop, L);
+    SpongeGeom g = {0, 0, 0, false};
+    if (live) g = sponge_geom(offsets, lengths, me, fixed_len, n_scalars, pad_mode);
+    if (g.bad && wv == 0 && bad_count != nullptr) atomicAdd(bad_count, 1);
+    const uint64_t trips = wave_max_u64(g.blocks);
+    const Fr one_mont = one_mont_word();
+    auto block_word = [&](uint64_t t) {                              // wave 1 + k: scalar 4t + k of the lane's message
+        Fr v = zero_word();
+        if (wv >= 1) {
+            const uint64_t idx = 4 * t + (uint64_t)(wv - 1);
+            if (idx < g.len)
+                v = load_word(scalars + (g.off + idx) * 32);
+            else if (pad_mode == 1 && idx == g.len && live)
+                v = one_mont;
+        }
+        return v;
+    };
+    Fr st = wv == 0 ? capacity : zero_word();
+    Fr dig = zero_word(), nxt = block_word(0);
+    __syncthreads();                                                 // the constants are in LDS
+#pragma unroll 1
+    for (uint64_t t = 0; t < trips; t++) {
+        if (wv >= 1) st = fr_add(st, nxt);
+        nxt = block_word(t + 1);
+        st = coop_finish(&d_coop, coop_rounds(&d_coop, L, wv, to_f29(st)));
+        if (t + 1 == g.blocks) dig = st;
+    }
+    if (wv == 1 && live) store_word(digests + me * 32, dig);
+}
+
+__global__ void __launch_bounds__(kCoopThreads) k_sponge_absorb_coop(uint8_t *states, const uint8_t *__restrict__ blocks,
+                                                                    size_t n, int blocks_each) {
+    __shared__ CoopLds L;
+    const int wv = coop_word_of_wave(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    const int lane = threadIdx.x & (kWave - 1);
+    const size_t me = (size_t)blockIdx.x * kCoopStates + lane;
+    const bool live = me < n;
+    coop_load_constants(&d_coop, L);
+    uint8_t *mine = states + (live ? me : 0) * 160 + wv * 32;
+    const uint8_t *blk = blocks + (live ? me : 0) * (size_t)blocks_each * 128 + (wv >= 1 ? wv - 1 : 0) * 32;
+    Fr st = load_word(mine), nxt = load_word(blk);
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < blocks_each; t++) {
+        if (wv >= 1) st = fr_add(st, nxt);
+        if (t + 1 < blocks_each) nxt = load_word(blk + (size_t)(t + 1) * 128);
+        st = coop_finish(&d_coop, coop_rounds(&d_coop, L, wv, to_f29(st)));
+    }
+    if (live) store_word(mine, st);
+}
+
+// incremental update, one level (see k_merkle_update_fast): lane = query, wave = state word
+template <int ARITY>
+__global__ void __launch_bounds__(kCoopThreads) k_merkle_update_coop(const uint8_t *__restrict__ children, size_t n_children,
+                                                                    uint8_t *__restrict__ parents,
+                                                                    const uint64_t *__restrict__ indices, size_t n_updates,
+                                                                    size_t n_leaves, uint64_t span, Fr tag, int out_idx,
+                                                                    const uint8_t *__restrict__ pad) {
+    __shared__ CoopLds L;
+    const int wv = coop_word_of_wave(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    const int lane = threadIdx.x & (kWave - 1);
+    const size_t q = (size_t)blockIdx.x * kCoopStates + lane;
+    coop_load_constants(&d_coop, L);
+    const UpdateWanted wanted{indices, n_leaves, span};
+    const bool mine = q < n_updates && wanted(q);
+    const size_t parent = mine ? indices[q] / span : 0;
+    Fr in = zero_word();
+    if (wv == 0) in = tag;
+    if (wv >= 1 && wv <= ARITY && mine) in = update_child<ARITY>(children, n_children, parent, wv - 1, pad);
+    __syncthreads();
+    const F29 fin = coop_rounds(&d_coop, L, wv, to_f29(in));
+    if (wv == out_idx && mine) store_word(parents + parent * 32, coop_finish(&d_coop, fin));
+}
+
+// path verification: the digest of a level leaves wave `out_idx` and enters the wave of its child position through LDS
+template <int ARITY>
+__global__ void __launch_bounds__(kCoopThreads) k_merkle_verify_coop(const uint8_t *__restrict__ leaves,
+                                                                    const uint64_t *__restrict__ indices,
+                                                                    const uint8_t *__restrict__ paths, size_t n_queries,
+                                                                    int depth, Fr tag, int out_idx,
+                                                                    uint8_t *__restrict__ roots) {
+    __shared__ CoopLds L;
+    const int wv = coop_word_of_wave(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    const int lane = threadIdx.x & (kWave - 1);
+    const size_t q = (size_t)blockIdx.x * kCoopStates + lane;
+    const bool live = q < n_queries;
+    coop_load_constants(&d_coop, L);
+    uint64_t idx = live ? indices[q] : 0;
+    const uint8_t *mine = paths + (live ? q : 0) * (size_t)depth * (ARITY - 1) * 32;
+    Fr node = load_word(leaves + (live ? q : 0) * 32);
+    auto sibling = [&](int l, uint64_t at) {                         // wave 1 + c: child c of level l, unless it is the node
+        Fr v = zero_word();
+        const int pos = (int)(at % ARITY), c = wv - 1;
+        if (wv >= 1 && wv <= ARITY && c != pos) v = load_word(mine + ((size_t)l * (ARITY - 1) + (c < pos ? c : c - 1)) * 32);
+        return v;
+    };
+    Fr sib = sibling(0, idx);
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 0; l < depth; l++) {
+        const int pos = (int)(idx % ARITY);
+        idx /= ARITY;
+        const Fr in = wv == 0 ? tag : (wv == pos + 1 ? node : sib);
+        if (l + 1 < depth) sib = sibling(l + 1, idx);
+        const F29 fin = coop_rounds(&d_coop, L, wv, to_f29(in));
+        if (wv == out_idx) {
+            const Fr o = coop_finish(&d_coop, fin);
+            uint4 *p = reinterpret_cast<uint4 *>(L.stage + lane * 32);
+            p[0] = make_uint4(o.l[0], o.l[1], o.l[2], o.l[3]);
+            p[1] = make_uint4(o.l[4], o.l[5], o.l[6], o.l[7]);
+        }
+        __syncthreads();
+        {
+            const uint4 *p = reinterpret_cast<const uint4 *>(L.stage + lane * 32);
+            const uint4 lo = p[0], hi = p[1];
+            node.l[0] = lo.x; node.l[1] = lo.y; node.l[2] = lo.z; node.l[3] = lo.w;
+            node.l[4] = hi.x; node.l[5] = hi.y; node.l[6] = hi.z; node.l[7] = hi.w;
+        }
+        __syncthreads();                                             // everyone has the digest before it is overwritten
+    }
+    if (wv == 0 && live) store_word(roots + q * 32, node);
+}
+
 // ---- ragged batches: counting sort of the message indices by block count --------------------------------
 // Three small launches over scratch = {counters[kSpongeBuckets + 1] (u32), order[n_msgs] (u32)}:
 //   count: histogram of min(blocks, kSpongeBuckets - 1);  scan: exclusive prefix sums (one block);  scatter: every
@@ -1268,7 +1415,8 @@ static void launch_merkle_coop(int arity, const uint8_t *children, uint8_t *out_
 #undef HADES_LAUNCH_COOP
 }
 
-// the ancestors of n_updates changed leaves on one level (k_merkle_update_*): one per wave up to kLanesMaxStates queries
+// the ancestors of n_updates changed leaves on one level (k_merkle_update_*): one per wave up to kLanesMaxStates
+// queries, five waves per ancestor up to kCoopMaxStates, one per lane above
 static void launch_merkle_update(int arity, const uint8_t *children, size_t n_children, uint8_t *parents,
                                  const uint64_t *indices, size_t n_updates, size_t n_leaves, uint64_t span, Fr tag,
                                  int out_idx, const uint8_t *pad, hipStream_t s) {
@@ -1277,7 +1425,11 @@ static void launch_merkle_update(int arity, const uint8_t *children, size_t n_ch
     const dim3 grid((unsigned)((n_updates + per_block - 1) / per_block)), block(kLanesWaves * kWave);
 #define HADES_LAUNCH_UPDATE(A)                                                                                          \
     do {                                                                                                                \
-        if (!lanes)                                                                                                     \
+        if (!lanes && n_updates <= kCoopMaxStates)                                                                      \
+            hipLaunchKernelGGL(k_merkle_update_coop<A>, dim3((unsigned)((n_updates + kCoopStates - 1) / kCoopStates)), \
+                               dim3(kCoopThreads), 0, s, children, n_children, parents, indices, n_updates, n_leaves,   \
+                               span, tag, out_idx, pad);                                                                \
+        else if (!lanes)                                                                                                \
             hipLaunchKernelGGL(k_merkle_update_fast<A>, dim3(blocks_for(n_updates)), dim3(kBlock), 0, s, children,     \
                                n_children, parents, indices, n_updates, n_leaves, span, tag, out_idx, pad);             \
         else if (helped)                                                                                                \
@@ -1993,6 +2145,13 @@ static int sponge_launch(const void *d_scalars, const uint64_t *d_offsets, const
         HIP_TRY(hipGetLastError());
         return HADES252_OK;
     }
+    if (n_msgs <= kCoopMaxStates && d_order == nullptr) {           // mid-size: five waves per message
+        hipLaunchKernelGGL(k_sponge_coop, dim3((unsigned)((n_msgs + kCoopStates - 1) / kCoopStates)), dim3(kCoopThreads), 0,
+                           (hipStream_t)stream, (const uint8_t *)d_scalars, d_offsets, d_lengths, (uint8_t *)d_digests,
+                           n_msgs, fixed_len, fr_from_u64(capacity_mont), pad_mode, n_scalars, d_bad_count);
+        HIP_TRY(hipGetLastError());
+        return HADES252_OK;
+    }
     hipLaunchKernelGGL(k_sponge, dim3(blocks_for(n_msgs)), dim3(kBlock), lds_for(4), (hipStream_t)stream,
                        (const uint8_t *)d_scalars, d_offsets, d_lengths, (uint8_t *)d_digests, n_msgs, fixed_len,
                        fr_from_u64(capacity_mont), pad_mode, n_scalars, d_bad_count, d_order);
@@ -2030,7 +2189,9 @@ int hades252_sponge_hash_var_ex_dev(const void *d_scalars, size_t n_scalars, con
         if (scratch_bytes < hades252_sponge_sort_scratch_bytes(n_msgs)) return HADES252_ERR_SCRATCH;
         if (misaligned(d_scratch)) return HADES252_ERR_INVALID_ARG;
     }
-    if (d_scratch != nullptr && n_msgs > kLanesMaxStates) {          // (one message per wave needs no sorting)
+    // up to kCoopMaxStates messages the batch is one round of blocks either way and takes as long as its longest message:
+    // the latency forms (one message per wave / five waves per message) are used and sorting buys nothing
+    if (d_scratch != nullptr && n_msgs > kCoopMaxStates) {
         hipStream_t s = (hipStream_t)stream;
         uint32_t *counters = (uint32_t *)d_scratch, *ord = counters + kSpongeBuckets + 4;
         HIP_TRY(hipMemsetAsync(counters, 0, (size_t)kSpongeBuckets * 4, s));
@@ -2080,6 +2241,13 @@ int hades252_sponge_absorb_dev(void *d_states, const void *d_blocks, size_t n_st
         else
             hipLaunchKernelGGL(k_sponge_absorb_lanes<false>, grid, block, 0, (hipStream_t)stream, (uint8_t *)d_states,
                                (const uint8_t *)d_blocks, n_states, blocks_each);
+        HIP_TRY(hipGetLastError());
+        return HADES252_OK;
+    }
+    if (n_states <= kCoopMaxStates) {
+        hipLaunchKernelGGL(k_sponge_absorb_coop, dim3((unsigned)((n_states + kCoopStates - 1) / kCoopStates)),
+                           dim3(kCoopThreads), 0, (hipStream_t)stream, (uint8_t *)d_states, (const uint8_t *)d_blocks,
+                           n_states, blocks_each);
         HIP_TRY(hipGetLastError());
         return HADES252_OK;
     }
@@ -2320,7 +2488,10 @@ int hades252_merkle_verify_dev(const void *d_leaves, const uint64_t *d_indices, 
     (const uint8_t *)d_leaves, d_indices, (const uint8_t *)d_paths, n_queries, depth, tag, out_idx, (uint8_t *)d_roots
 #define HADES_LAUNCH_VERIFY(A)                                                                                       \
     do {                                                                                                             \
-        if (!lanes)                                                                                                  \
+        if (!lanes && n_queries <= kCoopMaxStates)                                                                   \
+            hipLaunchKernelGGL(k_merkle_verify_coop<A>, dim3((unsigned)((n_queries + kCoopStates - 1) / kCoopStates)), \
+                               dim3(kCoopThreads), 0, (hipStream_t)stream, HADES_VERIFY_ARGS);                       \
+        else if (!lanes)                                                                                             \
             hipLaunchKernelGGL(k_merkle_verify<A>, dim3(blocks_for(n_queries)), dim3(kBlock), lds_for(1),           \
                                (hipStream_t)stream, HADES_VERIFY_ARGS);                                              \
         else if (helped)                                                                                             \

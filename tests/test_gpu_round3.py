@@ -482,21 +482,21 @@ def test_small_batch_sponge_one_message_per_wave(torch_cuda, hades_lib, H, oracl
     rng = random.Random(5 + pad)
     pool = oracle.gen_b(1234, 3000)
     dp = to_dev(torch, pool).view(-1, 4)
-    for n in (1, 2, 3, 4, 5, 100, 767, 768, 769, 1023, 1024, 1025):
+    for n in (1, 2, 3, 4, 5, 100, 767, 768, 769, 1023, 1024, 1025, 1100, 5000, 16383, 16384, 16385):
         lens = [rng.choice([0, 1, 2, 3, 4, 5, 7, 8, 9, 13, 40]) for _ in range(n)]
         offs = [rng.randrange(0, 3000 - l + 1) for l in lens]              # anywhere in the pool: messages overlap
         la, oa = np.array(lens, dtype=np.uint64), np.array(offs, dtype=np.uint64)
         exp = oracle.sponge_var(pool, oa, la, CAP, pad)
         got = to_host(H.sponge_hash_var(dp, to_dev(torch, oa), to_dev(torch, la), CAP, pad))
         assert (got == exp).all(), n
-        if n in (3, 768, 1024):
+        if n in (3, 768, 1024, 5000, 16385):
             assert (to_host(H.sponge_hash_var(dp, to_dev(torch, oa), to_dev(torch, la), CAP, pad, sort=True)) == exp).all()
     # one long message (750 blocks): the chain of dependent permutations the low-latency form is for
     one = oracle.sponge_var(pool, np.array([0], dtype=np.uint64), np.array([2999], dtype=np.uint64), CAP, pad)
     assert (to_host(H.sponge_hash_var(dp, to_dev(torch, np.array([0], dtype=np.uint64)),
                                       to_dev(torch, np.array([2999], dtype=np.uint64)), CAP, pad)) == one).all()
     # fixed length, few messages
-    for n, ln in ((1, 9), (7, 4), (770, 3), (1024, 1)):
+    for n, ln in ((1, 9), (7, 4), (770, 3), (1024, 1), (1025, 5), (16384, 2), (16385, 2)):
         msgs = oracle.gen_b(n + ln, n * ln)
         e = oracle.sponge(msgs, ln, CAP, pad)
         assert (to_host(H.sponge_hash(to_dev(torch, msgs).view(-1, 4), ln, CAP, pad)) == e).all(), (n, ln)
@@ -518,7 +518,7 @@ def test_small_batch_sponge_one_message_per_wave(torch_cuda, hades_lib, H, oracl
 
 def test_small_batch_streaming_absorb(torch_cuda, H, oracle):
     torch = torch_cuda
-    for n, t in ((1, 1), (1, 40), (3, 2), (4, 3), (767, 2), (769, 2), (1024, 1), (1025, 1)):
+    for n, t in ((1, 1), (1, 40), (3, 2), (4, 3), (767, 2), (769, 2), (1024, 1), (1025, 1), (1030, 3), (16384, 1), (16385, 1)):
         msgs = oracle.gen_b(31 * n + t, n * t * 4)
         exp = oracle.sponge(msgs, 4 * t, CAP, 0)
         st = H.SpongeStates(n, CAP)
@@ -526,8 +526,8 @@ def test_small_batch_streaming_absorb(torch_cuda, H, oracle):
         assert (to_host(st.squeeze()) == exp).all(), (n, t)
         # the whole state equals the per-lane kernel's (forced by a batch above the threshold sharing the first n states)
         if n <= 4:
-            big = H.SpongeStates(2000, CAP)
-            blocks = torch.zeros((2000, t, 4, 4), dtype=torch.int64, device="cuda")
+            big = H.SpongeStates(20000, CAP)
+            blocks = torch.zeros((20000, t, 4, 4), dtype=torch.int64, device="cuda")
             blocks[:n] = to_dev(torch, msgs).view(n, t, 4, 4)
             big.absorb(blocks)
             assert torch.equal(big.states[:n], st.states)
@@ -540,11 +540,15 @@ def test_small_batch_verify_one_query_per_wave(torch_cuda, H, oracle, arity):
     torch = torch_cuda
     tag = TAG[arity]
     if arity == 1:
-        chain = H.gen_b(1100, "cuda")
-        z = torch.zeros(1100, dtype=torch.int64, device="cuda")
-        e = torch.zeros((1100, 6, 0, 4), dtype=torch.int64, device="cuda")
+        chain = H.gen_b(17000, "cuda")
+        z = torch.zeros(17000, dtype=torch.int64, device="cuda")
+        e = torch.zeros((17000, 6, 0, 4), dtype=torch.int64, device="cuda")
         ref = H.merkle_verify(chain, z, e, 1, tag, 1)
-        for m in (1, 3, 768, 769, 1024):
+        cur = to_host(chain[:50])
+        for _ in range(6):
+            cur = oracle.merkle_level(cur, 1, tag, 1)
+        assert (to_host(ref[:50]) == cur).all()
+        for m in (1, 3, 768, 769, 1024, 1025, 16384):
             assert torch.equal(H.merkle_verify(chain[:m].contiguous(), z[:m].contiguous(), e[:m].contiguous(), 1, tag, 1), ref[:m])
         return
     n_leaves = arity ** 7 + 5
@@ -554,13 +558,13 @@ def test_small_batch_verify_one_query_per_wave(torch_cuda, H, oracle, arity):
     tree = H.merkle_build(leaves, arity, tag, 1, pad=pad)
     g = torch.Generator(device="cpu")
     g.manual_seed(arity)
-    idx = torch.randint(0, n_leaves, (1100,), generator=g, dtype=torch.int64).cuda()
+    idx = torch.randint(0, n_leaves, (17000,), generator=g, dtype=torch.int64).cuda()
     idx[0], idx[1] = n_leaves - 1, 0
     paths = H.merkle_open(leaves, tree, arity, idx, pad=pad)
     lv = leaves[idx].contiguous()
-    ref = H.merkle_verify(lv, idx, paths, arity, tag, 1)                      # 1100 queries: one per lane
+    ref = H.merkle_verify(lv, idx, paths, arity, tag, 1)                      # 17 000 queries: one per lane
     assert bool((ref == tree[-1:]).all())
-    for m in (1, 2, 3, 4, 767, 768, 769, 1024):
+    for m in (1, 2, 3, 4, 767, 768, 769, 1024, 1025, 5000, 16384, 16385):     # per wave / five waves per query / per lane
         r = H.merkle_verify(lv[:m].contiguous(), idx[:m].contiguous(), paths[:m].contiguous(), arity, tag, 1)
         assert torch.equal(r, ref[:m]), m
     bad = paths[:5].clone()
