@@ -763,12 +763,17 @@ __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
 }
 
 __device__ __forceinline__ Fr one_mont_word() {                    // 1 * 2^256 mod p
-    const uint32_t r1[8] = {0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau,
-                            0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u};
-    Fr one;
-#pragma unroll
-    for (int i = 0; i < 8; i++) one.l[i] = r1[i];
+    Fr one;                                                         // (member by member: a table would live in scratch)
+    one.l[0] = 0xfffffffeu; one.l[1] = 0x00000001u; one.l[2] = 0x00034802u; one.l[3] = 0x5884b7fau;
+    one.l[4] = 0xecbc4ff5u; one.l[5] = 0x998c4fefu; one.l[6] = 0xacc5056fu; one.l[7] = 0x1824b159u;
     return one;
+}
+// c ? a : b, limb by limb (v_cndmask; a ternary over whole scalars may be turned into a table in scratch)
+__device__ __forceinline__ Fr fr_select(bool c, const Fr &a, const Fr &b) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
 }
 
 __global__ void __launch_bounds__(kBlock, 3) k_sponge(const uint8_t *__restrict__ scalars,
@@ -908,7 +913,6 @@ __global__ void __launch_bounds__(kLanesWaves *kWave) k_sponge_lanes(const uint8
     const SpongeGeom g = sponge_geom(offsets, lengths, me, fixed_len, n_scalars, pad_mode);
     if constexpr (!HELPED) trips = g.blocks;
     if (g.bad && lane == 0 && bad_count != nullptr) atomicAdd(bad_count, 1);
-    const Fr one_mont = one_mont_word();
     auto block_word = [&](uint64_t t) {                              // lane 1 + k: scalar 4t + k of the message
         Fr v = zero_word();
         if (lane >= 1 && lane <= 4) {
@@ -916,7 +920,7 @@ __global__ void __launch_bounds__(kLanesWaves *kWave) k_sponge_lanes(const uint8
             if (idx < g.len)
                 v = load_word(scalars + (g.off + idx) * 32);
             else if (pad_mode == 1 && idx == g.len)
-                v = one_mont;
+                v = one_mont_word();
         }
         return v;
     };
@@ -1002,7 +1006,7 @@ __global__ void __launch_bounds__(kLanesWaves *kWave) k_merkle_verify_lanes(cons
     for (int l = 0; l < depth; l++) {
         const int pos = (int)(idx % ARITY);
         idx /= ARITY;
-        Fr in = lane == 0 ? tag : (lane == pos + 1 ? node : sib);
+        const Fr in = fr_select(lane == 0, tag, fr_select(lane == pos + 1, node, sib));
         if (l + 1 < depth) sib = sibling(l + 1, idx);                // in flight during the permutation
         const Fr out = lanes_perm<HELPED>(&d_lanes, L[wave], in);
 #pragma unroll
@@ -1040,7 +1044,6 @@ __global__ void __launch_bounds__(kCoopThreads) k_sponge_coop(const uint8_t *__r
     if (live) g = sponge_geom(offsets, lengths, me, fixed_len, n_scalars, pad_mode);
     if (g.bad && wv == 0 && bad_count != nullptr) atomicAdd(bad_count, 1);
     const uint64_t trips = wave_max_u64(g.blocks);
-    const Fr one_mont = one_mont_word();
     auto block_word = [&](uint64_t t) {                              // wave 1 + k: scalar 4t + k of the lane's message
         Fr v = zero_word();
         if (wv >= 1) {
@@ -1048,7 +1051,7 @@ __global__ void __launch_bounds__(kCoopThreads) k_sponge_coop(const uint8_t *__r
             if (idx < g.len)
                 v = load_word(scalars + (g.off + idx) * 32);
             else if (pad_mode == 1 && idx == g.len && live)
-                v = one_mont;
+                v = one_mont_word();
         }
         return v;
     };
@@ -1137,7 +1140,7 @@ __global__ void __launch_bounds__(kCoopThreads) k_merkle_verify_coop(const uint8
     for (int l = 0; l < depth; l++) {
         const int pos = (int)(idx % ARITY);
         idx /= ARITY;
-        const Fr in = wv == 0 ? tag : (wv == pos + 1 ? node : sib);
+        const Fr in = fr_select(wv == 0, tag, fr_select(wv == pos + 1, node, sib));
         if (l + 1 < depth) sib = sibling(l + 1, idx);
         const F29 fin = coop_rounds(&d_coop, L, wv, to_f29(in));
         if (wv == out_idx) {
