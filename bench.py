@@ -27,7 +27,8 @@ Also in the line:
                 workload; the same sample is used to check the GPU output bit for bit.
   secondary     outside `value`: BASELINE.json configs[3] (arity-4 Merkle tree over 2^24 leaves: tree
                 time, nodes/s, its own roofline with 160 B per node), `single_perm` (ONE permutation: device
-                and host-call latency), and `host_path`: the entry point a
+                and host-call latency), `sponge_chain` (one message of 1000 blocks: us per dependent
+                permutation), and `host_path`: the entry point a
                 Rust `Strategy::perm` binds (`hades252_perm_batch`: host memory in, host memory out,
                 PCIe-inclusive) on 2^22 states against this box's measured bidirectional copy ceiling.
 `--workload merkle` times the tree build itself as the step (development; the driver runs the default).
@@ -215,6 +216,29 @@ def merkle_record(H, torch, device, log_leaves: int, reps: int = 5):
             "root": "".join("%016x" % (int(v) & 0xFFFFFFFFFFFFFFFF) for v in reversed(root.cpu().tolist())),
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_node": MERKLE_BYTES_PER_NODE}}, leaves
+
+
+def sponge_chain_record(H, torch, device, blocks=1000):
+    """The reference's consumer (dusk-poseidon's sponge, README.md:9) at its hardest shape for a GPU: ONE message, a chain
+    of `blocks` dependent permutations.  Whole call (HIP events), microseconds per block; the CPU port's time for one
+    permutation on one thread is what a CPU core would need per block."""
+    pool = H.gen_b(4 * blocks, device)
+    off = torch.zeros(1, dtype=torch.int64, device=device)
+    ln = torch.full((1,), 4 * blocks - 1, dtype=torch.int64, device=device)      # + the padding scalar = `blocks` blocks
+    cap = 1                                                                      # any capacity word: timing only
+    H.sponge_hash_var(pool, off, ln, cap, 1)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        H.sponge_hash_var(pool, off, ln, cap, 1)
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = sorted(ts)[2]
+    return {"workload": "sponge hash of ONE message of %d blocks (rate 4): %d dependent permutations, one wave" % (blocks, blocks),
+            "ms": ms, "us_per_block": ms * 1e3 / blocks}
 
 
 def single_perm_record(H, torch, device):
@@ -417,6 +441,7 @@ def main():
             del leaves
             torch.cuda.empty_cache()
             sec["single_perm"] = single_perm_record(H, torch, device)
+            sec["sponge_chain"] = sponge_chain_record(H, torch, device)
             sec["host_path"] = host_path_record(22)
         except Exception as e:                       # secondary records never take the headline down
             sec["error"] = repr(e)

@@ -36,6 +36,7 @@ def test_bench_single_and_two_ranks_agree():
     assert hp["bit_exact_vs_device_path"] is True and 0 < hp["frac_of_ceiling"] < 1.2 and hp["perms"] == 1 << 22
     sp = one["secondary"]["single_perm"]
     assert 20 < sp["device_us_median"] < 150 and sp["device_us_min"] <= sp["host_call_us_median"] < 400
+    assert 20 < one["secondary"]["sponge_chain"]["us_per_block"] < 150
     assert one["config"]["kernel"] == "k_perm_fast" and "valu_issue" in one and "frac_of_measured" not in one["valu_issue"]
     assert one["n_gpus"] == 1 and one["parity_vs_cpu_sample"] is True
     assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1
