@@ -23,6 +23,7 @@ STAMP = LIB + ".stamp"
 LOCK = LIB + ".lock"
 SOURCES = ["hades252.hip"]
 DEPS = ["hades252.hip", "fr32.hpp", "staging.hpp", "hades_literal.hpp", "hades_fast.hpp", "k_perm_fast.hpp", "hades_coop.hpp", "hades_lanes.hpp",
+        "device_tables.hpp", "kernels_perm.hpp", "kernels_merkle.hpp", "kernels_sponge.hpp", "kernels_aux.hpp",
         "hades_constants.inc", os.path.join("..", "..", "include", "hades252.h")]
 # what the dominant kernel (k_perm_fast) is made of: profiles recorded for it stay valid while these are unchanged
 PERM_FAST_DEPS = ["fr32.hpp", "staging.hpp", "hades_fast.hpp", "k_perm_fast.hpp"]

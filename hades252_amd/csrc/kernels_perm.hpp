@@ -1,0 +1,386 @@
+// kernels_perm.hpp -- permutation kernels other than k_perm_fast: the literal schedule, per-round trace, gadget witness, per-operation kernels, field ops, wire format, five waves per state, one state per wave
+// Part of the single translation unit hades252.hip (included there after device_tables.hpp); not a stand-alone header.
+#pragma once
+
+template <int OP>
+__global__ void __launch_bounds__(kBlock) k_states_literal(uint8_t *states, size_t n, int cursor) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<5>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr st[5];
+    wave_load_records<5>(states, rec0, n, slab, st);
+    LiteralView V{d_ark_mont, d_mds_mont};
+    if constexpr (OP == OP_PERM) lit_perm(V, st);
+    if constexpr (OP == OP_ARK) lit_add_round_key(V, cursor, st);
+    if constexpr (OP == OP_MDS) lit_mul_matrix(V, st);
+    if constexpr (OP == OP_FULL) lit_full_round(V, cursor, st);
+    if constexpr (OP == OP_PARTIAL) lit_partial_round(V, cursor, st);
+    wave_store_records<5>(states, rec0, n, slab, st);
+}
+
+// Per-round trace: the state after every round (what the PLONK gadget needs as witnesses,
+// reference src/strategies/gadget.rs:41-133), round-major: trace[r] is a whole AoS batch.
+// Literal variant (the reference's schedule; parity anchor for the fast one).
+__global__ void __launch_bounds__(kBlock) k_perm_trace_literal(const uint8_t *__restrict__ states,
+                                                               uint8_t *__restrict__ trace, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<5>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr st[5];
+    wave_load_records<5>(states, rec0, n, slab, st);
+    LiteralView V{d_ark_mont, d_mds_mont};
+#pragma unroll 1
+    for (int r = 0; r < 67; r++) {
+        if (r < 4 || r >= 63)
+            lit_full_round(V, 5 * r, st);
+        else
+            lit_partial_round(V, 5 * r, st);
+        wave_store_records<5>(trace + (size_t)r * n * 160, rec0, n, slab, st);
+    }
+}
+
+// Scale-tracked trace (the shipped one): the rounds of k_perm_fast; after each round every word is
+// brought back to the in-memory BlsScalar with ONE constant product (U_r = 2^256 * Rp / s_{r+1},
+// hades252_amd/_derive.py), a full reduction, and -- in partial rounds, whose word 0..3 constants the
+// schedule defers -- one field addition of the known offset D_r: 5 extra products per round instead of
+// the literal schedule's 28 / 40 full-width products.
+__global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__restrict__ states,
+                                                               uint8_t *__restrict__ trace, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<5>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    F29 st[5];
+    {
+        Fr in[5];
+        wave_load_records<5>(states, rec0, n, slab, in);
+#pragma unroll
+        for (int w = 0; w < 5; w++) st[w] = to_f29(in[w]);
+    }
+#pragma unroll 1
+    for (int r = 0; r < 67; r++) {
+        fast_round(d_fast.round[r], r < 4 || r >= 63, st);
+        const int32_t *u = d_trace_u[r];
+#pragma unroll
+        for (int w = 0; w < 5; w++) {
+            Fr v = finalize(mont_mul_const(st[w], u));
+            if (r >= 4 && r < 63) v = fr_add(v, load_const(d_trace_d[r], w));
+            slab_put<5>(slab, w, v);
+        }
+        slab_flush<5>(trace + (size_t)r * n * 160, rec0, n, slab);
+    }
+}
+
+// Full gadget witness: EVERY gate output of the reference's GadgetStrategy for every state -- the 972 values a
+// PLONK prover assigns per permutation (src/strategies/gadget.rs:41-133: round-0 key additions, v^2 / v^4 / v^5 of
+// each S-box, and per linear layer the 3-term partial sums r1[j] and the rows r2[j] with the NEXT round's constant
+// appended).  Wire-major output: wires[g] is a batch of n scalars (32 B, in-memory BlsScalar), g in gate order.
+// The rounds are those of k_perm_fast; each value is un-scaled with one constant product, fully reduced and, where
+// the shipped schedule defers constants, corrected by a known offset (hades252_amd/_derive.py::witness_schedule;
+// limb-exact replay: tests/test_fast_model.py::witness_model).  Loops over words rotate the state so that every
+// piece of code exists once (I-cache).
+__device__ __forceinline__ void store_wire(uint8_t *wires, size_t n, int wire, size_t rec, bool live, const Fr &v) {
+    if (live) {
+        uint4 *q = reinterpret_cast<uint4 *>(wires + ((size_t)wire * n + rec) * 32);
+        q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+        q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock, 3) k_perm_witness(const uint8_t *__restrict__ states,
+                                                            uint8_t *__restrict__ wires, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<5>(lds);
+    const size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    const size_t rec = rec0 + (threadIdx.x & (kWave - 1));
+    const bool live = rec < n;
+    F29 st[5];
+    {
+        Fr in[5];
+        wave_load_records<5>(states, rec0, n, slab, in);
+#pragma unroll
+        for (int w = 0; w < 5; w++) st[w] = to_f29(in[w]);
+    }
+    int wire = 0;
+#pragma unroll 1
+    for (int r = 0; r < 67; r++) {
+        const int32_t *rc = d_fast.round[r];
+        const int32_t *u = d_wit.u[r];
+        const bool full = r < 4 || r >= 63;
+        if (full) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) add_lazy(st[w], rc + w * kNL);
+        }
+        add_lazy(st[4], rc + 4 * kNL);
+        if (r == 0) {
+#pragma unroll 1
+            for (int i = 0; i < 5; i++) {               // state after the first round key: word 4 - i sits at st[4]
+                store_wire(wires, n, wire + 4 - i, rec, live, finalize(mont_mul_const(st[4], u)));
+                rotate_right(st);
+            }
+            wire += 5;
+        }
+        // S-boxes: v^2, v^4, v^5 (partial round: word 4 only, then the K_r product that re-scales it)
+        const int cnt = full ? 5 : 1;
+#pragma unroll 1
+        for (int i = 0; i < cnt; i++) {
+            const int w = full ? 4 - i : 0;             // gate order: word 0 first (a partial round has one S-box)
+            const F29 v2 = mont_sqr(st[4]);
+            store_wire(wires, n, wire + 3 * w, rec, live, finalize(mont_mul_const(v2, u + kNL)));
+            const F29 v4 = mont_sqr(v2);
+            store_wire(wires, n, wire + 3 * w + 1, rec, live, finalize(mont_mul_const(v4, u + 2 * kNL)));
+            F29 v5 = mont_mul(v4, st[4]);
+            if (!full) v5 = mont_mul_const(v5, rc + 5 * kNL);
+            store_wire(wires, n, wire + 3 * w + 2, rec, live, finalize(mont_mul_const(v5, u + 3 * kNL)));
+            st[4] = v5;
+            if (full) rotate_right(st);
+#pragma unroll
+            for (int k = 0; k < kNL; k++) limb_fence(st[4].l[k]);
+        }
+        wire += 3 * cnt;
+        // r1[j] = M[j][0] z0 + M[j][1] z1 + M[j][2] z2: three columns of the small-integer layer, one-limb step
+#pragma unroll 1
+        for (int j = 0; j < 5; j++) {
+            const int32_t c0 = d_coop.mds[j][0], c1 = d_coop.mds[j][1], c2 = d_coop.mds[j][2];
+            F29 y;
+            int64_t acc = 0;
+            mac(acc, st[0].l[0], c0);
+            mac(acc, st[1].l[0], c1);
+            mac(acc, st[2].l[0], c2);
+            const int32_t m = (int32_t)((uint32_t)acc & kMask29);
+            acc >>= kLB;
+#pragma unroll
+            for (int k = 1; k < kNL; k++) {
+                mac(acc, st[0].l[k], c0);
+                mac(acc, st[1].l[k], c1);
+                mac(acc, st[2].l[k], c2);
+                mac(acc, m, NEGP29[k]);
+                y.l[k - 1] = (int32_t)((uint32_t)acc & kMask29);
+                acc >>= kLB;
+            }
+            y.l[kNL - 1] = (int32_t)acc;
+            Fr v = finalize(mont_mul_const(y, u + 4 * kNL));
+            if (!full) v = fr_add(v, load_const(d_wit.d[r], j));
+            store_wire(wires, n, wire + 2 * j, rec, live, v);
+        }
+        small_mds(st);
+        // r2[j] = row j of the linear layer + the next round's constant
+#pragma unroll 1
+        for (int i = 0; i < 5; i++) {
+            const int j = 4 - i;
+            Fr v = finalize(mont_mul_const(st[4], u + 5 * kNL));
+            v = fr_add(v, load_const(d_wit.d[r], 5 + j));
+            store_wire(wires, n, wire + 2 * j + 1, rec, live, v);
+            rotate_right(st);
+#pragma unroll
+            for (int k = 0; k < kNL; k++) limb_fence(st[4].l[k]);
+        }
+        wire += 10;
+#pragma unroll
+        for (int w = 0; w < 5; w++)
+#pragma unroll
+            for (int k = 0; k < kNL; k++) limb_fence(st[w].l[k]);
+    }
+}
+
+// Generic batched BlsScalar operations (reference call sites src/strategies/scalar.rs:28,33,44;
+// src/round_constants.rs:41): out[i] = a[i] (op) b[i] on Montgomery limbs, fully reduced.
+// IMPL 0: the saturated 8 x u32 CIOS arithmetic of fr32.hpp (what the literal kernels use);
+// IMPL 1: the radix-2^29 signed-limb arithmetic of the shipped kernel (to_f29, mont_fips, finalize).
+// These exist so that tests can drive BOTH device arithmetics through the computations that produced
+// the reference's constant blobs (tests/test_gpu_blob_kat.py), and as a13's batched surface.
+enum FrOp { FR_ADD = 0, FR_MUL = 1, FR_SQUARE = 2, FR_FROM_RAW = 3 };
+template <int IMPL>
+__global__ void __launch_bounds__(kBlock) k_fr_op(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, int op) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<1>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr x[1], y[1];
+    wave_load_records<1>(a, rec0, n, slab, x);
+    if (op == FR_ADD || op == FR_MUL) {
+        wave_load_records<1>(b, rec0, n, slab, y);
+    } else if (op == FR_SQUARE) {
+        y[0] = x[0];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) y[0].l[i] = d_r2[i];
+    }
+    Fr r[1];
+    if constexpr (IMPL == 0) {
+        r[0] = (op == FR_ADD) ? fr_add(x[0], y[0]) : fr_mul(x[0], y[0]);
+    } else {
+        F29 xa = to_f29(x[0]), yb = to_f29(y[0]);
+        if (op == FR_ADD) {
+            add_lazy(xa, yb.l);                                    // limbs < 2^30
+            r[0] = finalize(mont_mul_const(xa, d_rp_mod_p));       // (a + b) * Rp / Rp
+        } else {
+            F29 t = (op == FR_SQUARE) ? mont_sqr(xa) : mont_mul(xa, yb);   // a b / Rp
+            r[0] = finalize(mont_mul_const(t, d_rp2_over_r));      // * (Rp^2 / 2^256) / Rp = a b / 2^256
+        }
+    }
+    wave_store_records<1>(out, rec0, n, slab, r);
+}
+
+// The trait's per-operation methods on the radix-2^29 path: same field elements as the literal forms above (kept
+// for add_round_key, which is five additions), a sixth to a tenth of the instructions -- mul_matrix is the
+// small-integer layer + one un-scaling product per word instead of 25 full products.  Round keys are added in the
+// memory format first (any cursor over all 960 constants), so the result of every method is the unique reduced
+// BlsScalar, bit-identical to the literal kernels and the oracle.
+template <int OP>
+__global__ void __launch_bounds__(kBlock, 3) k_states_fast(uint8_t *states, size_t n, int cursor) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<5>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr in[5];
+    wave_load_records<5>(states, rec0, n, slab, in);
+    if constexpr (OP != OP_MDS) {
+        LiteralView V{d_ark_mont, d_mds_mont};
+        lit_add_round_key(V, cursor, in);
+    }
+    F29 st[5];
+#pragma unroll
+    for (int w = 0; w < 5; w++) st[w] = to_f29(in[w]);
+    if constexpr (OP == OP_FULL) {
+#pragma unroll 1
+        for (int i = 0; i < 5; i++) {                 // one S-box body, the state rotates through it
+            st[4] = sbox29(st[4]);
+            rotate_right(st);
+#pragma unroll
+            for (int k = 0; k < kNL; k++) limb_fence(st[4].l[k]);
+        }
+    }
+    if constexpr (OP == OP_PARTIAL) st[4] = mont_mul_const(sbox29(st[4]), d_op_k);
+    small_mds(st);
+    const int32_t *u = OP == OP_FULL ? d_op_w_full : d_op_w;
+    Fr out[5];
+#pragma unroll
+    for (int w = 0; w < 5; w++) out[w] = finalize(mont_mul_const(st[w], u));
+    wave_store_records<5>(states, rec0, n, slab, out);
+}
+
+__global__ void __launch_bounds__(kBlock) k_sbox(uint8_t *scalars, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<1>(lds);
+    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    Fr st[1];
+    wave_load_records<1>(scalars, rec0, n, slab, st);
+    st[0] = finalize(mont_mul_const(sbox29(to_f29(st[0])), d_op_k));
+    wave_store_records<1>(scalars, rec0, n, slab, st);
+}
+
+// canonical bytes <-> Montgomery limbs (BlsScalar::from_bytes / to_bytes): 64 B of HBM traffic and ONE constant
+// product per scalar.  The product runs on the radix-2^29 path (mont_mul_const: 153 multiply-adds; the saturated
+// 8x32 product these kernels used in round 1 is ~620 instructions and made them VALU-bound at 3.4-4.5 TB/s).
+// No LDS: every lane reads and writes its own 32 bytes with two 16-byte accesses -- a wave's two instructions
+// together cover 2 KiB contiguous, the second hits the lines the first fetched -- and takes kWirePerThread scalars
+// in a grid-stride loop to keep more bytes in flight.  `out` may be `in` (lane-private in-place update).
+constexpr int kWirePerThread = 4;
+constexpr int32_t kRpOverR = 1 << (kLB * kNL - 256);        // 2^261 / 2^256
+template <int MODE>   // 0 = to_bytes (x / 2^256), 1 = from_bytes (a * 2^256, inputs >= p rejected)
+__global__ void __launch_bounds__(kBlock) k_wire(const uint8_t *in, uint8_t *out, size_t n, int *bad_count) {
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    const int32_t *factor = MODE == 1 ? d_rp_times_r : d_rp_over_r;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(in + i * 32);
+        uint4 lo = p[0], hi = p[1];
+        Fr a;
+        a.l[0] = lo.x; a.l[1] = lo.y; a.l[2] = lo.z; a.l[3] = lo.w;
+        a.l[4] = hi.x; a.l[5] = hi.y; a.l[6] = hi.z; a.l[7] = hi.w;
+        // to_bytes: the factor Rp / 2^256 = 32 is a single limb: 81 multiply-adds instead of 153 (5.0 -> 5.3 TB/s at 2^26
+        // scalars; issuing the next scalar's loads before this one's arithmetic changed nothing: profiles/r3/wire_bw.txt)
+        Fr m = finalize(MODE == 1 ? mont_mul_const(to_f29(a), factor) : mont_mul_small(to_f29(a), kRpOverR));
+        if (MODE == 1 && !fr_is_canonical(a)) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) m.l[k] = 0;
+            if (bad_count != nullptr) atomicAdd(bad_count, 1);
+        }
+        uint4 *q = reinterpret_cast<uint4 *>(out + i * 32);
+        q[0] = make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]);
+        q[1] = make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]);
+    }
+}
+
+// ---- low-latency kernels: five waves per state (hades_coop.hpp) --------------------------------------
+// In-place permutation of up to 64 states per 320-thread block.
+__global__ void __launch_bounds__(kCoopThreads) k_perm_coop(uint8_t *states, size_t n) {
+    __shared__ CoopLds L;
+    const int wv = coop_word_of_wave(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));   // the word this wave owns
+    const int lane = threadIdx.x & (kWave - 1);
+    const size_t rec0 = (size_t)blockIdx.x * kCoopStates;
+    const size_t total = n * 10, chunk0 = rec0 * 10;
+    uint4 *g = reinterpret_cast<uint4 *>(states + rec0 * 160);
+    coop_load_constants(&d_coop, L);
+#pragma unroll
+    for (int c = threadIdx.x; c < kCoopStates * 10; c += kCoopThreads) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (chunk0 + c < total) v = g[c];
+        const int rec = c / 10, part = c - rec * 10;
+        *reinterpret_cast<uint4 *>(L.stage + rec * 176 + part * 16) = v;
+    }
+    __syncthreads();
+    Fr w;
+    {
+        const uint4 *p = reinterpret_cast<const uint4 *>(L.stage + lane * 176 + wv * 32);
+        uint4 lo = p[0], hi = p[1];
+        w.l[0] = lo.x; w.l[1] = lo.y; w.l[2] = lo.z; w.l[3] = lo.w;
+        w.l[4] = hi.x; w.l[5] = hi.y; w.l[6] = hi.z; w.l[7] = hi.w;
+    }
+    const F29 fin = coop_rounds(&d_coop, L, wv, to_f29(w));     // 67 barriers: everyone has read `stage` by now
+    const Fr o = coop_finish(&d_coop, fin);
+    {
+        uint4 *p = reinterpret_cast<uint4 *>(L.stage + lane * 176 + wv * 32);
+        p[0] = make_uint4(o.l[0], o.l[1], o.l[2], o.l[3]);
+        p[1] = make_uint4(o.l[4], o.l[5], o.l[6], o.l[7]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = threadIdx.x; c < kCoopStates * 10; c += kCoopThreads) {
+        const int rec = c / 10, part = c - rec * 10;
+        uint4 v = *reinterpret_cast<const uint4 *>(L.stage + rec * 176 + part * 16);
+        if (chunk0 + c < total) g[c] = v;
+    }
+}
+
+// ---- lowest-latency kernels: one state per WAVE, every field element spread over a 16-lane row (hades_lanes.hpp) ---
+// Two forms, four waves per block (one per SIMD) either way:
+//   HELPED   three states per block + a helper wave that owns word 3 of all three during the full rounds (its S-box then
+//            runs beside the main waves' instead of doubling their instruction stream): 50 us -- up to 768 states, one
+//            block per CU;
+//   plain    four states per block, every wave does everything itself: 54 us -- for 769 .. 1 024 states, where the helped
+//            form would put a second block on some CUs.
+constexpr int kLanesWaves = 4;
+struct LanesAlways {
+    __device__ __forceinline__ bool operator()(size_t) const { return true; }
+};
+// `wanted(rec)` (wave-uniform) lets a kernel drop records it does not need; such a wave idles like one past the end
+template <bool HELPED, class Wanted = LanesAlways>
+__device__ __forceinline__ bool lanes_role(LanesLds *L, size_t n, size_t &rec, Wanted wanted = Wanted()) {
+    const int wave = threadIdx.x >> 6;                                                   // false: this wave is done
+    if constexpr (HELPED) {
+        if (wave == kLanesWaves - 1) {
+            lanes_helper<kLanesWaves - 1>(&d_lanes, *reinterpret_cast<LanesLds(*)[kLanesWaves - 1]>(L));
+            return false;
+        }
+        rec = (size_t)blockIdx.x * (kLanesWaves - 1) + wave;
+        if (rec >= n || !wanted(rec)) {
+            lanes_idle();
+            return false;
+        }
+        return true;
+    } else {
+        rec = (size_t)blockIdx.x * kLanesWaves + wave;
+        return rec < n && wanted(rec);                               // no block-wide barrier anywhere: idle waves leave
+    }
+}
+
+// In-place permutation, one state per wave.
+template <bool HELPED>
+__global__ void __launch_bounds__(kLanesWaves *kWave) k_perm_lanes(uint8_t *states, size_t n) {
+    __shared__ LanesLds L[kLanesWaves];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    size_t rec;
+    if (!lanes_role<HELPED>(L, n, rec)) return;
+    uint8_t *mine = states + rec * 160 + (lane < 5 ? lane : 0) * 32;
+    const Fr in = lane < 5 ? load_word(mine) : zero_word();
+    const Fr out = lanes_perm<HELPED>(&d_lanes, L[wave], in);
+    if (lane < 5) store_word(mine, out);
+}
