@@ -34,7 +34,8 @@ def H(hades_lib):
 
 
 def to_dev(torch, arr):
-    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint64).view(np.int64)).cuda()
+    a = np.ascontiguousarray(arr, dtype=np.uint64)
+    return torch.from_numpy((a if a.flags.writeable else a.copy()).view(np.int64)).cuda()
 
 
 def to_host(t):
