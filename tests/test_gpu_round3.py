@@ -578,3 +578,39 @@ def test_small_batch_verify_one_query_per_wave(torch_cuda, H, oracle, arity):
     hl = to_host(lv[:3]).reshape(3, 4)
     for q in range(3):
         assert (oracle.merkle_verify_path(hl[q], int(idx[q].item()), hp[q], arity, tag, 3) == r3[q]).all()
+
+
+def test_device_entry_points_are_graph_capturable(torch_cuda, H, oracle):
+    """The _dev entry points only enqueue work on the caller's stream (no allocation, no synchronisation, no host read-back),
+    so a launch-bound chain -- here a whole 4^6-leaf tree (six dependent levels), a small sponge batch and an in-place
+    permutation -- can be captured once in a hipGraph and replayed on new data."""
+    torch = torch_cuda
+    tag = TAG[4]
+    n = 4 ** 6
+    leaves = H.gen_b(n, "cuda")
+    states = H.gen_b(5 * 100, "cuda").view(100, 5, 4)
+    scratch = torch.empty(max(H._lib.lib().hades252_merkle_scratch_bytes(n, 4) // 8, 2), dtype=torch.int64, device="cuda")
+    strat = H.ScalarStrategy()
+    root_e = H.merkle_root(leaves, 4, tag, 1, scratch)                       # eager, also warms everything up
+    dig_e = H.sponge_hash(leaves[:400], 4, CAP, 1)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            root_g = H.merkle_root(leaves, 4, tag, 1, scratch)
+            dig_g = H.sponge_hash(leaves[:400], 4, CAP, 1)
+            strat.perm(states)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(root_g, root_e) and torch.equal(dig_g, dig_e)
+    # new data in the same buffers, replayed: equals the oracle
+    fresh = oracle.gen_b(4242, n)
+    leaves.copy_(to_dev(torch, fresh).view(-1, 4))
+    st0 = oracle.gen_b(777, 500)
+    states.copy_(to_dev(torch, st0).view(100, 5, 4))
+    g.replay()
+    torch.cuda.synchronize()
+    assert (to_host(root_g) == oracle.merkle_tree(fresh, 4, tag, 1)[-1]).all()
+    assert (to_host(dig_g) == oracle.sponge(fresh[: 400 * 4], 4, CAP, 1)).all()
+    assert (to_host(states) == oracle.perm_batch(st0)).all()
