@@ -43,6 +43,15 @@ SIGNATURES = {
     "hades252_host_register": (c_int, [c_void_p, c_size_t]),
     "hades252_host_unregister": (c_int, [c_void_p]),
     "hades252_host_is_pinned": (c_int, [c_void_p, c_size_t]),
+    "hades252_dev_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "hades252_dev_free": (c_int, [c_void_p]),
+    "hades252_dev_upload": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hades252_dev_download": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hades252_stream_create": (c_int, [POINTER(c_void_p)]),
+    "hades252_stream_destroy": (c_int, [c_void_p]),
+    "hades252_stream_sync": (c_int, [c_void_p]),
+    "hades252_merkle_root": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_uint64), c_int, c_void_p, c_void_p]),
+    "hades252_sponge_hash": (c_int, [c_void_p, c_size_t, c_size_t, POINTER(c_uint64), c_int, c_void_p]),
     "hades252_perm_trace_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "hades252_perm_trace_dev_ex": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
     "hades252_witness_wires": (c_int, []),

@@ -353,6 +353,8 @@ struct HostPipe {
     hipEvent_t in_done[kPipeSlots] = {}, k_done[kPipeSlots] = {}, out_done[kPipeSlots] = {};
     void *pinned = nullptr;       // small-call staging: page-locked host memory the kernels access directly
     void *pinned_dev = nullptr;   // ... and its device-side address
+    void *aux = nullptr;          // grow-only device arena of the one-shot Merkle / sponge calls (levels, digests, tables)
+    size_t aux_cap = 0;
 };
 // Calls of at most this many states skip both DMA copies: the states are copied (by the CPU) into a
 // page-locked buffer that the kernel reads and writes over PCIe itself -- one launch + one synchronisation.
@@ -363,6 +365,7 @@ static std::vector<HostPipe> g_pool;
 static void destroy_pipe(HostPipe &p) {
     if (p.pinned) (void)hipHostFree(p.pinned);
     if (p.buf) (void)hipFree(p.buf);
+    if (p.aux) (void)hipFree(p.aux);
     for (int i = 0; i < kPipeSlots; i++) {
         if (p.in_done[i]) (void)hipEventDestroy(p.in_done[i]);
         if (p.k_done[i]) (void)hipEventDestroy(p.k_done[i]);
@@ -1296,5 +1299,212 @@ int hades252_digest_dev(const void *d_words, uint64_t first_index, size_t n_u64,
     HIP_TRY(hipGetLastError());
     return HADES252_OK;
 }
+
+// ---- device memory for callers without HIP bindings ------------------------------------------------
+int hades252_dev_alloc(void **d_ptr, size_t bytes) {
+    if (d_ptr == nullptr || bytes == 0) return HADES252_ERR_INVALID_ARG;
+    *d_ptr = nullptr;
+    int rc = check_device();
+    if (rc != HADES252_OK) return rc;
+    HIP_TRY(hipMalloc(d_ptr, bytes));
+    return HADES252_OK;
+}
+
+int hades252_dev_free(void *d_ptr) {
+    if (d_ptr == nullptr) return HADES252_OK;
+    HIP_TRY(hipFree(d_ptr));
+    return HADES252_OK;
+}
+
+int hades252_dev_upload(void *d_dst, const void *h_src, size_t bytes, void *stream) {
+    if (bytes == 0) return HADES252_OK;
+    if (d_dst == nullptr || h_src == nullptr) return HADES252_ERR_INVALID_ARG;
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return HADES252_OK;
+}
+
+int hades252_dev_download(void *h_dst, const void *d_src, size_t bytes, void *stream) {
+    if (bytes == 0) return HADES252_OK;
+    if (h_dst == nullptr || d_src == nullptr) return HADES252_ERR_INVALID_ARG;
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return HADES252_OK;
+}
+
+int hades252_stream_create(void **stream) {
+    if (stream == nullptr) return HADES252_ERR_INVALID_ARG;
+    *stream = nullptr;
+    int rc = check_device();
+    if (rc != HADES252_OK) return rc;
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return HADES252_OK;
+}
+
+int hades252_stream_destroy(void *stream) {
+    if (stream == nullptr) return HADES252_OK;
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return HADES252_OK;
+}
+
+int hades252_stream_sync(void *stream) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return HADES252_OK;
+}
+
+// ---- the callers of perm on host memory ----------------------------------------------------------------------
+// Input travels host -> device in chunks on the pipe's copy stream while the previous chunk is hashed on its kernel
+// stream (the pipe of the host-pointer perm path: same streams, chunk buffers and events); what travels back is 32 bytes
+// per tree / message.  Big pageable inputs are page-locked for the duration of the call like hades252_perm_batch does.
+static size_t host_chunk_bytes() {
+    static const size_t forced = []() -> size_t {
+        const char *e = getenv("HADES252_HOST_CHUNK_BYTES");
+        return e ? (size_t)strtoull(e, nullptr, 0) : 0;
+    }();
+    return forced ? forced : (size_t)32 << 20;
+}
+
+static int pipe_ensure_aux(HostPipe &p, size_t bytes) {
+    if (p.aux_cap >= bytes) return HADES252_OK;
+    if (p.aux) (void)hipFree(p.aux);
+    p.aux = nullptr;
+    p.aux_cap = 0;
+    HIP_TRY(hipMalloc(&p.aux, bytes));
+    p.aux_cap = bytes;
+    return HADES252_OK;
+}
+
+// page-lock a big input the caller has not pinned (read-only use); returns whether it has to be unlocked afterwards
+static bool pin_input_for_call(const void *h, size_t bytes) {
+    const char *e = getenv("HADES252_HOST_PIN");
+    if ((e && e[0] == '0') || bytes < ((size_t)8 << 20) || host_range_pinned(h, bytes)) return false;
+    if (hipHostRegister(const_cast<void *>(h), bytes, hipHostRegisterDefault) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
+struct HostCall {                 // releases what a one-shot host call holds, whichever way it ends
+    HostPipe pipe;
+    const void *registered = nullptr;
+    bool have_pipe = false;
+    int finish(int code) {
+        if (have_pipe) {
+            (void)hipStreamSynchronize(pipe.s_in);
+            (void)hipStreamSynchronize(pipe.s_k);
+            (void)hipStreamSynchronize(pipe.s_out);
+            (void)hipGetLastError();
+            release_pipe(pipe);
+            have_pipe = false;
+        }
+        if (registered) (void)hipHostUnregister(const_cast<void *>(registered));
+        registered = nullptr;
+        return code;
+    }
+};
+
+#define TRY_CALL(call, expr)                           \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) {                        \
+            tl_last_hip_error = (int)e_;               \
+            (void)hipGetLastError();                   \
+            return (call).finish(HADES252_ERR_HIP);    \
+        }                                              \
+    } while (0)
+
+int hades252_merkle_root(const uint64_t *leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
+                         const uint64_t *pad, uint64_t root[4]) {
+    const int depth = hades252_merkle_depth(n_leaves, arity);
+    if (leaves == nullptr || root == nullptr || tag_mont == nullptr || depth < 1 || out_idx < 0 || out_idx >= 5)
+        return HADES252_ERR_INVALID_ARG;
+    int rc = check_device();
+    if (rc != HADES252_OK) return rc;
+    size_t chunk = host_chunk_bytes() / 32;                           // leaves per chunk, a multiple of the arity
+    chunk -= chunk % arity;
+    if (chunk < (size_t)arity) chunk = arity;
+    if (chunk > n_leaves) chunk = n_leaves;
+    const size_t n1 = (n_leaves + arity - 1) / arity;
+    const size_t scratch = hades252_merkle_scratch_bytes(n1, arity);  // 0 unless the tree over level 1 has >= 2 levels
+    const size_t head = (size_t)depth * 32 + 32;                      // padding table, root
+    HostCall call;
+    rc = acquire_pipe(chunk * 32, call.pipe);
+    if (rc != HADES252_OK) return rc;
+    call.have_pipe = true;
+    HostPipe &pp = call.pipe;
+    rc = pipe_ensure_aux(pp, head + n1 * 32 + scratch);
+    if (rc != HADES252_OK) return call.finish(rc);
+    uint8_t *d_pad = (uint8_t *)pp.aux, *d_root = d_pad + (size_t)depth * 32, *d_l1 = d_pad + head;
+    uint8_t *buf_a = d_l1 + n1 * 32, *buf_b = buf_a + ((n1 + arity - 1) / arity) * 32;
+    const Fr tag = fr_from_u64(tag_mont);
+    if (pad != nullptr) TRY_CALL(call, hipMemcpyAsync(d_pad, pad, (size_t)depth * 32, hipMemcpyHostToDevice, pp.s_k));
+    const uint8_t *dp = pad != nullptr ? d_pad : nullptr;
+    if (pin_input_for_call(leaves, n_leaves * 32)) call.registered = leaves;
+    const uint8_t *h = (const uint8_t *)leaves;
+    const size_t n_chunks = (n_leaves + chunk - 1) / chunk;
+    for (size_t c = 0; c < n_chunks; c++) {                           // level 1, chunk by chunk behind the copies
+        const int k = (int)(c % kPipeSlots);
+        const size_t off = c * chunk, n = n_leaves - off < chunk ? n_leaves - off : chunk;
+        uint8_t *d = (uint8_t *)pp.buf + (size_t)k * pp.slot_cap;
+        if (c >= (size_t)kPipeSlots) TRY_CALL(call, hipEventSynchronize(pp.k_done[k]));   // chunk c - kPipeSlots is hashed
+        TRY_CALL(call, hipMemcpyAsync(d, h + off * 32, n * 32, hipMemcpyHostToDevice, pp.s_in));
+        TRY_CALL(call, hipEventRecord(pp.in_done[k], pp.s_in));
+        TRY_CALL(call, hipStreamWaitEvent(pp.s_k, pp.in_done[k], 0));
+        launch_merkle_any(arity, d, n, n1 == 1 ? d_root : d_l1 + (off / arity) * 32, tag, out_idx, dp, pp.s_k);
+        TRY_CALL(call, hipGetLastError());
+        TRY_CALL(call, hipEventRecord(pp.k_done[k], pp.s_k));
+    }
+    if (n1 > 1) {
+        rc = merkle_run(d_l1, n1, arity, nullptr, buf_a, buf_b, d_root, tag, out_idx, dp != nullptr ? dp + 32 : nullptr,
+                        pp.s_k);
+        if (rc != HADES252_OK) return call.finish(rc);
+    }
+    TRY_CALL(call, hipMemcpyAsync(root, d_root, 32, hipMemcpyDeviceToHost, pp.s_k));
+    TRY_CALL(call, hipStreamSynchronize(pp.s_k));
+    return call.finish(HADES252_OK);
+}
+
+int hades252_sponge_hash(const uint64_t *msgs, size_t n_msgs, size_t msg_len, const uint64_t capacity_mont[4],
+                         int pad_mode, uint64_t *digests) {
+    if (n_msgs == 0) return HADES252_OK;
+    if (digests == nullptr || capacity_mont == nullptr || (msgs == nullptr && msg_len > 0) ||
+        (pad_mode != 0 && pad_mode != 1) || (msg_len > 0 && n_msgs > (SIZE_MAX / 32) / msg_len))
+        return HADES252_ERR_INVALID_ARG;
+    int rc = check_device();
+    if (rc != HADES252_OK) return rc;
+    const size_t msg_bytes = msg_len * 32;
+    size_t chunk = msg_bytes ? host_chunk_bytes() / msg_bytes : n_msgs;                  // messages per chunk
+    if (chunk == 0) chunk = 1;
+    if (chunk > n_msgs) chunk = n_msgs;
+    if (chunk > kMaxLaunchRecords) chunk = kMaxLaunchRecords;
+    HostCall call;
+    rc = acquire_pipe(chunk * msg_bytes > 16 ? chunk * msg_bytes : 16, call.pipe);
+    if (rc != HADES252_OK) return rc;
+    call.have_pipe = true;
+    HostPipe &pp = call.pipe;
+    rc = pipe_ensure_aux(pp, (size_t)kPipeSlots * chunk * 32);                           // digests of the chunks in flight
+    if (rc != HADES252_OK) return call.finish(rc);
+    if (msg_bytes && pin_input_for_call(msgs, n_msgs * msg_bytes)) call.registered = msgs;
+    const uint8_t *h = (const uint8_t *)msgs;
+    uint8_t *out = (uint8_t *)digests;
+    const size_t n_chunks = (n_msgs + chunk - 1) / chunk;
+    for (size_t c = 0; c < n_chunks; c++) {
+        const int k = (int)(c % kPipeSlots);
+        const size_t off = c * chunk, n = n_msgs - off < chunk ? n_msgs - off : chunk;
+        uint8_t *d = (uint8_t *)pp.buf + (size_t)k * pp.slot_cap, *dd = (uint8_t *)pp.aux + (size_t)k * chunk * 32;
+        if (c >= (size_t)kPipeSlots) TRY_CALL(call, hipEventSynchronize(pp.out_done[k]));
+        if (msg_bytes) TRY_CALL(call, hipMemcpyAsync(d, h + off * msg_bytes, n * msg_bytes, hipMemcpyHostToDevice, pp.s_in));
+        TRY_CALL(call, hipEventRecord(pp.in_done[k], pp.s_in));
+        TRY_CALL(call, hipStreamWaitEvent(pp.s_k, pp.in_done[k], 0));
+        rc = sponge_launch(d, nullptr, nullptr, n, msg_len, capacity_mont, pad_mode, dd, pp.s_k, n * msg_len, nullptr, nullptr);
+        if (rc != HADES252_OK) return call.finish(rc);
+        TRY_CALL(call, hipEventRecord(pp.k_done[k], pp.s_k));
+        TRY_CALL(call, hipStreamWaitEvent(pp.s_out, pp.k_done[k], 0));
+        TRY_CALL(call, hipMemcpyAsync(out + off * 32, dd, n * 32, hipMemcpyDeviceToHost, pp.s_out));
+        TRY_CALL(call, hipEventRecord(pp.out_done[k], pp.s_out));
+    }
+    TRY_CALL(call, hipStreamSynchronize(pp.s_out));
+    return call.finish(HADES252_OK);
+}
+#undef TRY_CALL
 
 }  // extern "C"

@@ -257,6 +257,44 @@ def perm_multi(data: np.ndarray, n_workers: int = 0, virtual: bool = False) -> N
                                                   n_workers, _lib.MULTI_VIRTUAL if virtual else 0), "perm_multi")
 
 
+def _host_u64(a, what: str) -> np.ndarray:
+    if not isinstance(a, np.ndarray) or a.dtype != np.uint64 or not a.flags["C_CONTIGUOUS"]:
+        raise TypeError("%s: host buffers must be C-contiguous numpy uint64" % what)
+    return a
+
+
+def merkle_root_host(leaves: np.ndarray, arity: int, tag_mont: int, out_idx: int = 1, pad: np.ndarray | None = None) -> np.ndarray:
+    """``hades252_merkle_root``: root (4 limbs) of the tree over leaves held in HOST memory (n x 4 uint64); the leaves travel
+    to the device in chunks while the first tree level is hashed behind them.  ``pad``: host table [depth, 4] or None."""
+    leaves = _host_u64(leaves, "merkle_root_host")
+    if leaves.size % 4:
+        raise ValueError("merkle_root_host: %d limbs is not a whole number of scalars" % leaves.size)
+    n = leaves.size // 4
+    depth = merkle_depth(n, arity, "merkle_root_host")
+    pptr = None
+    if pad is not None:
+        pad = _host_u64(pad, "merkle_root_host")
+        if pad.size != depth * 4:
+            raise ValueError("merkle_root_host: the padding table needs %d digests" % depth)
+        pptr = pad.ctypes.data_as(ctypes.c_void_p)
+    root = np.zeros(4, dtype=np.uint64)
+    check(_lib.lib().hades252_merkle_root(leaves.ctypes.data_as(ctypes.c_void_p), n, arity, _tag_arr(tag_mont), out_idx,
+                                          pptr, root.ctypes.data_as(ctypes.c_void_p)), "merkle_root_host")
+    return root
+
+
+def sponge_hash_host(msgs: np.ndarray, n_msgs: int, msg_len: int, capacity_mont: int, pad_mode: int = 1) -> np.ndarray:
+    """``hades252_sponge_hash``: digests [n_msgs, 4] of n_msgs fixed-length messages held in HOST memory."""
+    msgs = _host_u64(msgs, "sponge_hash_host")
+    if msgs.size != n_msgs * msg_len * 4:
+        raise ValueError("sponge_hash_host: buffer is not %d messages of %d scalars" % (n_msgs, msg_len))
+    out = np.zeros((n_msgs, 4), dtype=np.uint64)
+    check(_lib.lib().hades252_sponge_hash(msgs.ctypes.data_as(ctypes.c_void_p) if msgs.size else None, n_msgs, msg_len,
+                                          _tag_arr(capacity_mont), pad_mode, out.ctypes.data_as(ctypes.c_void_p)),
+          "sponge_hash_host")
+    return out
+
+
 def perm_trace(states_t, kernel: int = _lib.KERNEL_DEFAULT, out=None):
     """State after every round (round-major: result[r] is the batch after round r); the input is
     left untouched.  Witness pre-computation for the reference's GadgetStrategy

@@ -110,6 +110,33 @@ int hades252_host_register(void *p, size_t bytes);
 int hades252_host_unregister(void *p);
 int hades252_host_is_pinned(const void *p, size_t bytes);
 
+/* ---- device memory for callers that do not link HIP themselves -----------------------------------------
+ * A Rust crate binding only this library can keep its data resident and use every *_dev entry point through these:
+ *   hades252_dev_alloc / _free   device memory on the current device (hipMalloc / hipFree)
+ *   hades252_dev_upload          host -> device on `stream` (NULL = the default stream); asynchronous when the host memory
+ *   hades252_dev_download        is page-locked (hades252_host_alloc / _register), device -> host likewise
+ *   hades252_stream_create / _destroy / _sync    a stream handle for the `stream` arguments (sync(NULL) = the default one)
+ * Pointers and streams are plain HIP objects: a HIP program may mix them with its own. */
+int hades252_dev_alloc(void **d_ptr, size_t bytes);
+int hades252_dev_free(void *d_ptr);
+int hades252_dev_upload(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int hades252_dev_download(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int hades252_stream_create(void **stream);
+int hades252_stream_destroy(void *stream);
+int hades252_stream_sync(void *stream);
+
+/* ---- the callers of perm, host memory in, host memory out -------------------------------------------------
+ * One-shot forms of the Merkle root and the fixed-length sponge for data that lives in host memory (page-locked or not,
+ * as for hades252_perm_batch): the leaves / messages travel to the device in chunks while the previous chunk is being
+ * hashed (the first tree level / the sponge itself), only 32 bytes per tree / message travel back.
+ *   hades252_merkle_root   leaves: n_leaves x 4 u64 (Montgomery limbs); pad: NULL or depth x 4 u64 (the padding table of
+ *                          hades252_merkle_root_pad_dev, host memory); semantics of hades252_merkle_root_pad_dev
+ *   hades252_sponge_hash   msgs: n_msgs x msg_len x 4 u64; digests: n_msgs x 4 u64; semantics of hades252_sponge_hash_dev */
+int hades252_merkle_root(const uint64_t *leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
+                         const uint64_t *pad, uint64_t root[4]);
+int hades252_sponge_hash(const uint64_t *msgs, size_t n_msgs, size_t msg_len, const uint64_t capacity_mont[4],
+                         int pad_mode, uint64_t *digests);
+
 /* Per-round trace (witness pre-computation for GadgetStrategy, src/strategies/gadget.rs:41-133):
  * d_trace receives 67 batches, round-major: trace[r] (n_perms x 160 B, same AoS format) is the
  * state of every permutation after round r's mul_matrix; trace[66] equals the perm output.

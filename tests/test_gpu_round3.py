@@ -614,3 +614,84 @@ def test_device_entry_points_are_graph_capturable(torch_cuda, H, oracle):
     assert (to_host(root_g) == oracle.merkle_tree(fresh, 4, tag, 1)[-1]).all()
     assert (to_host(dig_g) == oracle.sponge(fresh[: 400 * 4], 4, CAP, 1)).all()
     assert (to_host(states) == oracle.perm_batch(st0)).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# the callers of perm on HOST memory, and device memory for callers without HIP bindings
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("chunk_bytes", [None, "4096", "100000"])
+def test_host_merkle_root_and_sponge(torch_cuda, H, oracle, monkeypatch, chunk_bytes):
+    """hades252_merkle_root / hades252_sponge_hash: host memory in, 32 bytes per tree / message out; chunked upload behind
+    the hashing (tiny chunks force many slot reuses and ragged last chunks).  The chunk size is latched at first use, so
+    the forced sizes run in child interpreters."""
+    import subprocess, textwrap
+    if chunk_bytes is not None:
+        code = textwrap.dedent('''
+            import os, sys
+            sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, os.path.join(%r, "oracle"))
+            import numpy as np
+            from hades252_amd import strategy as H
+            import hades_spec as S
+            import oracle_lib
+            o = oracle_lib.load()
+            tag = S.to_mont(15); cap = S.to_mont(1 << 64)
+            for arity, n in ((4, 1000), (3, 5000), (2, 777), (4, 4), (4, 5)):
+                lv = o.gen_b(n, n)
+                assert (H.merkle_root_host(lv, arity, S.to_mont(2 ** arity - 1)) == o.merkle_tree(lv, arity, S.to_mont(2 ** arity - 1), 1)[-1]).all(), (arity, n)
+            for n, ln in ((1000, 3), (50, 40), (3, 1000)):
+                m = o.gen_b(n + ln, n * ln)
+                assert (H.sponge_hash_host(m, n, ln, cap, 1).reshape(-1) == o.sponge(m, ln, cap, 1)).all(), (n, ln)
+            print("child ok")
+        ''') % (ROOT, ROOT, ROOT)
+        env = dict(os.environ, HADES252_HOST_CHUNK_BYTES=chunk_bytes)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "child ok" in r.stdout, r.stderr[-3000:]
+        return
+    for arity, n in ((4, 4 ** 8), (4, 100001), (3, 3 ** 9), (2, 2), (2, 3), (4, 4 ** 10 + 17), (2, 2 ** 20)):
+        tag = TAG[arity]
+        lv = oracle.gen_b(n + arity, n)
+        depth = H.merkle_depth(n, arity)
+        opad = oracle.merkle_empty_digests(arity, depth, S.to_mont(9), tag, 1)
+        dev = to_dev(torch_cuda, lv).view(-1, 4)
+        dpad = to_dev(torch_cuda, opad).view(depth, 4)
+        assert (H.merkle_root_host(lv, arity, tag) == to_host(H.merkle_root(dev, arity, tag, 1))).all(), (arity, n)
+        assert (H.merkle_root_host(lv, arity, tag, 3, pad=opad.reshape(depth, 4).copy()) ==
+                to_host(H.merkle_root(dev, arity, tag, 3, pad=dpad))).all(), (arity, n)
+        if n <= 100001:
+            assert (H.merkle_root_host(lv, arity, tag, 1, pad=opad.reshape(depth, 4).copy()) ==
+                    oracle.merkle_tree(lv, arity, tag, 1, opad)[-1]).all(), (arity, n)
+    for n, ln, pad in ((1, 1, 1), (5, 0, 1), (1000, 7, 0), (70000, 4, 1), (3, 3000, 1), (1 << 18, 3, 1)):
+        m = oracle.gen_b(3 * n + ln, n * ln)
+        got = H.sponge_hash_host(m, n, ln, CAP, pad)
+        if ln:
+            exp = to_host(H.sponge_hash(to_dev(torch_cuda, m).view(-1, 4), ln, CAP, pad))
+            assert (got.reshape(-1) == exp).all(), (n, ln)
+        if ln == 0:                                                           # n empty messages
+            z = np.zeros(n, dtype=np.uint64)
+            assert (got.reshape(-1) == oracle.sponge_var(np.zeros(4, dtype=np.uint64), z, z, CAP, pad)).all()
+        elif n * ln <= 300000:
+            assert (got.reshape(-1) == oracle.sponge(m, ln, CAP, pad)).all(), (n, ln)
+    with pytest.raises(Exception):
+        H.merkle_root_host(oracle.gen_b(1, 1), 4, TAG[4])                         # one leaf is not a tree
+    with pytest.raises(Exception):
+        H.merkle_root_host(oracle.gen_b(1, 8), 5, TAG[4])
+
+
+def test_device_memory_helpers_without_torch_allocations(hades_lib, oracle):
+    """A caller with no HIP bindings: allocate, upload, permute on its own stream, download -- only through the library."""
+    n = 3000
+    inp = oracle.gen_b(606, 5 * n)
+    out = np.zeros_like(inp)
+    d, s = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hades_lib.hades252_dev_alloc(ctypes.byref(d), inp.nbytes) == 0 and d.value
+    assert hades_lib.hades252_stream_create(ctypes.byref(s)) == 0 and s.value
+    assert hades_lib.hades252_dev_upload(d, inp.ctypes.data_as(ctypes.c_void_p), inp.nbytes, s) == 0
+    assert hades_lib.hades252_perm_batch_dev(d, n, s) == 0
+    assert hades_lib.hades252_dev_download(out.ctypes.data_as(ctypes.c_void_p), d, out.nbytes, s) == 0
+    assert hades_lib.hades252_stream_sync(s) == 0
+    assert (out == oracle.perm_batch(inp)).all()
+    assert hades_lib.hades252_stream_destroy(s) == 0 and hades_lib.hades252_dev_free(d) == 0
+    assert hades_lib.hades252_dev_free(None) == 0 and hades_lib.hades252_stream_destroy(None) == 0
+    assert hades_lib.hades252_dev_alloc(None, 16) == -1 and hades_lib.hades252_dev_alloc(ctypes.byref(d), 0) == -1
+    assert hades_lib.hades252_dev_upload(None, inp.ctypes.data_as(ctypes.c_void_p), 16, None) == -1
+    assert hades_lib.hades252_stream_sync(None) == 0

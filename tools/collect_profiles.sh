@@ -22,5 +22,6 @@ cp $G/time_paths_$TAG.txt $P/time_paths.txt
 cp $G/lanes_proto_$TAG.txt $P/lanes_proto.txt
 cp $G/pcie_probe_$TAG.txt $P/pcie_probe.txt
 cp $G/residency_$TAG.txt $P/residency.txt
+cp $G/host_callers_$TAG.txt $P/host_callers.txt
 tail -6 $G/pytest_gpu_$TAG.txt > $P/pytest_gpu_summary.txt
 ls -la $P

@@ -15,6 +15,7 @@ timeout 120 ./build_tools/pcie_probe 640 > gpurun_out/pcie_probe_$TAG.txt 2>&1; 
 timeout 300 ./build_tools/residency > gpurun_out/residency_$TAG.txt 2>&1; echo "residency rc=$?"
 timeout 120 ./build_tools/dfma_proto > gpurun_out/dfma_proto_$TAG.txt 2>&1; echo "dfma rc=$?"
 timeout 900 python tools/time_paths.py > gpurun_out/time_paths_$TAG.txt 2>&1; echo "time_paths rc=$?"
+timeout 300 ./build_tools/host_path_bench callers > gpurun_out/host_callers_$TAG.txt 2>&1; echo "host callers rc=$?"
 timeout 600 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"
 bash tools/profile_round.sh $TAG > gpurun_out/profile_round_$TAG.log 2>&1; echo "profile rc=$?"
 timeout 600 python bench.py > gpurun_out/bench_${TAG}_after_profile.json 2>> gpurun_out/bench_$TAG.err; echo "bench2 rc=$?"

@@ -53,7 +53,89 @@ static double ceiling_seconds(size_t bytes, double *h2d_alone, double *d2h_alone
     return best[2];
 }
 
+// `callers`: the one-shot host forms of the Merkle root and the sponge (hades252_merkle_root / hades252_sponge_hash)
+// against their device-resident twins and the one-way copy rate of the same bytes
+static int callers() {
+    const uint64_t tag[4] = {0x00000020ffffffdfull, 0x348ddb9d00362421ull, 0x658b26f6c2232750ull, 0x0e5d6e47a2b2d9b1ull};  // 15 R mod p
+    const uint64_t cap[4] = {1, 0, 0, 0};
+    for (int logn : {16, 20, 24}) {
+        const size_t n = (size_t)1 << logn, bytes = n * 32;
+        uint64_t *lv;
+        HK(hades252_host_alloc((void **)&lv, bytes));
+        void *d, *d_scr, *d_root;
+        CK(hipMalloc(&d, bytes));
+        CK(hipMalloc(&d_scr, hades252_merkle_scratch_bytes(n, 4) + 64));
+        CK(hipMalloc(&d_root, 32));
+        HK(hades252_gen_b_dev(d, 0, n, 0x4861646573323532ull, nullptr));
+        CK(hipMemcpy(lv, d, bytes, hipMemcpyDeviceToHost));
+        uint64_t want[4], got[4];
+        double td = 1e9, th = 1e9, tp = 1e9, tc = 1e9;
+        for (int rep = 0; rep < 5; rep++) {
+            CK(hipDeviceSynchronize());
+            double t0 = now();
+            HK(hades252_merkle_root_dev(d, n, 4, d_scr, hades252_merkle_scratch_bytes(n, 4), tag, 1, d_root, nullptr));
+            CK(hipDeviceSynchronize());
+            td = std::min(td, now() - t0);
+            t0 = now();
+            CK(hipMemcpy(d, lv, bytes, hipMemcpyHostToDevice));
+            tc = std::min(tc, now() - t0);
+        }
+        CK(hipMemcpy(want, d_root, 32, hipMemcpyDeviceToHost));
+        for (int rep = 0; rep < 5; rep++) {
+            double t0 = now();
+            HK(hades252_merkle_root(lv, n, 4, tag, 1, nullptr, got));
+            th = std::min(th, now() - t0);
+        }
+        bool ok = memcmp(want, got, 32) == 0;
+        std::vector<uint64_t> plain(lv, lv + n * 4);
+        for (int rep = 0; rep < 3; rep++) {
+            double t0 = now();
+            HK(hades252_merkle_root(plain.data(), n, 4, tag, 1, nullptr, got));
+            tp = std::min(tp, now() - t0);
+        }
+        ok = ok && memcmp(want, got, 32) == 0;
+        printf("merkle root, arity 4, 2^%d leaves in HOST memory: page-locked %.3f ms, pageable %.3f ms;  device-resident %.3f ms, "
+               "bare upload of the leaves %.3f ms (%.1f GB/s);  roots equal: %s\n",
+               logn, th * 1e3, tp * 1e3, td * 1e3, tc * 1e3, bytes / tc / 1e9, ok ? "yes" : "NO");
+        fflush(stdout);
+        HK(hades252_host_free(lv));
+        CK(hipFree(d)); CK(hipFree(d_scr)); CK(hipFree(d_root));
+    }
+    for (int logn : {10, 16, 22}) {
+        const size_t n = (size_t)1 << logn, len = 4, bytes = n * len * 32;
+        uint64_t *ms, *dg;
+        HK(hades252_host_alloc((void **)&ms, bytes));
+        HK(hades252_host_alloc((void **)&dg, n * 32));
+        void *d, *d_dig;
+        CK(hipMalloc(&d, bytes));
+        CK(hipMalloc(&d_dig, n * 32));
+        HK(hades252_gen_b_dev(d, 0, n * len, 0x4861646573323532ull, nullptr));
+        CK(hipMemcpy(ms, d, bytes, hipMemcpyDeviceToHost));
+        double td = 1e9, th = 1e9;
+        for (int rep = 0; rep < 5; rep++) {
+            CK(hipDeviceSynchronize());
+            double t0 = now();
+            HK(hades252_sponge_hash_dev(d, n, len, cap, 1, d_dig, nullptr));
+            CK(hipDeviceSynchronize());
+            td = std::min(td, now() - t0);
+            t0 = now();
+            HK(hades252_sponge_hash(ms, n, len, cap, 1, dg));
+            th = std::min(th, now() - t0);
+        }
+        std::vector<uint64_t> want(n * 4);
+        CK(hipMemcpy(want.data(), d_dig, n * 32, hipMemcpyDeviceToHost));
+        printf("sponge, 2^%d messages of 4 scalars (2 permutations each) in HOST memory: %.3f ms = %.1f M hashes/s (%.1f GB/s in);  "
+               "device-resident %.3f ms;  digests equal: %s\n",
+               logn, th * 1e3, n / th / 1e6, bytes / th / 1e9, td * 1e3, memcmp(want.data(), dg, n * 32) == 0 ? "yes" : "NO");
+        fflush(stdout);
+        HK(hades252_host_free(ms)); HK(hades252_host_free(dg));
+        CK(hipFree(d)); CK(hipFree(d_dig));
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && strcmp(argv[1], "callers") == 0) return callers();
     std::vector<int> logs;
     for (int i = 1; i < argc; i++) logs.push_back(atoi(argv[i]));
     if (logs.empty()) logs = {20, 22, 24};
