@@ -16,6 +16,7 @@ cp $G/prof_$TAG/hbm_traffic.json profiles/hbm_traffic.json
 cp $G/prof_$TAG/pmc_summary.json $P/pmc_summary.json
 cp $G/prof_$TAG/summary.txt $P/rocprofv3_bench_2p26_summary.txt
 cp $G/prof_$TAG/latency_kernel_stats.csv $P/latency_kernel_stats.csv
+cp $G/prof_$TAG/latency_kernel_instructions.txt $P/latency_kernel_instructions.txt
 find $G/prof_$TAG/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $P/kernel_stats.csv
 cp $G/prof_$TAG/wire_bw.txt $P/wire_bw_last_session.txt
 cp $G/time_paths_$TAG.txt $P/time_paths.txt

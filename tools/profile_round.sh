@@ -17,6 +17,29 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUS
 # the latency kernels on one state + the 2^16-leaf tree (kernel durations only)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_latency -- python3 tools/lat_one.py > /dev/null 2> $OUT/trace_latency.log
 find $OUT/trace_latency -name "*kernel_stats.csv" | head -1 | xargs cat > $OUT/latency_kernel_stats.csv
+# ... and their instruction counts (VALU instructions per wave: the latency of a lone wave IS its instruction count)
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_latency -- python3 tools/lat_one.py > /dev/null 2> $OUT/pmc_latency.log
+python3 - "$OUT" <<'PY' > $OUT/latency_kernel_instructions.txt 2>&1
+import csv, glob, os, sys
+out = sys.argv[1]
+acc = {}
+for f in glob.glob(os.path.join(out, "pmc_latency", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "").split("(")[0]
+        if not k.startswith(("k_", "void k_", "hades::k_")):
+            continue
+        d = acc.setdefault((k, r.get("Grid_Size", "")), {})
+        d.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+print("kernel, grid (threads): per-dispatch averages of SQ_WAVES, and VALU / SALU / LDS instructions PER WAVE")
+for (k, g), d in sorted(acc.items()):
+    w = sum(d.get("SQ_WAVES", [0])) / max(len(d.get("SQ_WAVES", [1])), 1)
+    def per_wave(name):
+        v = d.get(name)
+        return (sum(v) / len(v)) / w if v and w else float("nan")
+    print("%-46s grid %-8s n=%-4d waves %6.0f  VALU/wave %9.0f  SALU/wave %8.0f  LDS/wave %7.0f"
+          % (k[:46], g, len(d.get("SQ_WAVES", [])), w, per_wave("SQ_INSTS_VALU"), per_wave("SQ_INSTS_SALU"), per_wave("SQ_INSTS_LDS")))
+PY
+cat $OUT/latency_kernel_instructions.txt
 python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # wire-format kernels beyond the Infinity Cache, with HBM byte counters
