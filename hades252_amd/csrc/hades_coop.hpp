@@ -99,7 +99,8 @@ __device__ __forceinline__ void coop_constants(const CoopLds &L, int r, int wv, 
 // The 67 rounds on one word per wave.  `mine` = this wave's word of this lane's state (to_f29 of the
 // in-memory BlsScalar); returns the final word, still scaled (finalize(mont_mul_const(., final_f)) yields
 // the BlsScalar).  wv (the word this wave owns) is wave-uniform.  One block-wide barrier per round: all five
-// waves must call it together, after coop_load_constants + a barrier.
+// waves must call it together, after coop_load_constants + a barrier.  A kernel that calls it again (chains of
+// permutations) puts a barrier between the calls: round 66 and the next round 0 use the same exchange buffer.
 //   own step (S-box, or the G_r product for words 0..3 of a partial round) -> publish -> barrier -> read the
 //   other four words -> own row.  The next round's constants are fetched from LDS before the step, so their
 //   latency is hidden; ping-pong exchange buffers make one barrier per round sufficient.

@@ -256,6 +256,7 @@ __global__ void __launch_bounds__(kCoopThreads) k_sponge_coop(const uint8_t *__r
         nxt = block_word(t + 1);
         st = coop_finish(&d_coop, coop_rounds(&d_coop, L, wv, to_f29(st)));
         if (t + 1 == g.blocks) dig = st;
+        __syncthreads();      // the last round's exchange buffer is the next permutation's first: everyone has read it
     }
     if (wv == 1 && live) store_word(digests + me * 32, dig);
 }
@@ -277,6 +278,7 @@ __global__ void __launch_bounds__(kCoopThreads) k_sponge_absorb_coop(uint8_t *st
         if (wv >= 1) st = fr_add(st, nxt);
         if (t + 1 < blocks_each) nxt = load_word(blk + (size_t)(t + 1) * 128);
         st = coop_finish(&d_coop, coop_rounds(&d_coop, L, wv, to_f29(st)));
+        __syncthreads();      // (as in k_sponge_coop)
     }
     if (live) store_word(mine, st);
 }

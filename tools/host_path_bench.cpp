@@ -70,13 +70,15 @@ static int callers() {
         CK(hipMemcpy(lv, d, bytes, hipMemcpyDeviceToHost));
         uint64_t want[4], got[4];
         double td = 1e9, th = 1e9, tp = 1e9, tc = 1e9;
-        for (int rep = 0; rep < 5; rep++) {
+        for (int rep = 0; rep < 7; rep++) {
             CK(hipDeviceSynchronize());
             double t0 = now();
             HK(hades252_merkle_root_dev(d, n, 4, d_scr, hades252_merkle_scratch_bytes(n, 4), tag, 1, d_root, nullptr));
             CK(hipDeviceSynchronize());
             td = std::min(td, now() - t0);
-            t0 = now();
+        }
+        for (int rep = 0; rep < 5; rep++) {
+            double t0 = now();
             CK(hipMemcpy(d, lv, bytes, hipMemcpyHostToDevice));
             tc = std::min(tc, now() - t0);
         }
