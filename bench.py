@@ -57,6 +57,8 @@ PEAK_CLOCK_HZ = 2.4e9
 # (MI355X_MICROARCH.md).  IDEAL peak = one 64-bit op per SIMD per 4 cycles at the 2.4 GHz peak clock.
 VALU_IDEAL_G_WI = N_SIMD * PEAK_CLOCK_HZ / 4 / 1e9  # 614.4 G 64-bit wave-instr/s
 MERKLE_BYTES_PER_NODE = 160        # 4 x 32 B children in + 32 B digest out
+LANES_MAX_STATES = 1 << 10         # hades252.hip kLanesMaxStates / kRowsMaxStates: one state per wave / per 16-lane row
+ROWS_MAX_STATES = 1 << 12
 COOP_MAX_STATES = 1 << 14          # hades252.hip kCoopMaxStates: DEFAULT dispatch picks the five-waves kernel up to here
 
 
@@ -182,11 +184,11 @@ def kernel_of(kernel_arg: int, n: int) -> str:
     from hades252_amd import _lib
     if kernel_arg == _lib.KERNEL_LITERAL:
         return "k_states_literal"
-    if kernel_arg == _lib.KERNEL_COOP or (kernel_arg == _lib.KERNEL_DEFAULT and n <= COOP_MAX_STATES):
-        return "k_perm_coop"
-    if kernel_arg == getattr(_lib, "KERNEL_LANES", -1):
-        return "k_perm_lanes"
-    return "k_perm_fast"
+    if kernel_arg == _lib.KERNEL_DEFAULT:                                  # hades252_perm_batch_dev_ex's own rule
+        kernel_arg = (_lib.KERNEL_LANES if n <= LANES_MAX_STATES else _lib.KERNEL_ROWS if n <= ROWS_MAX_STATES
+                      else _lib.KERNEL_COOP if n <= COOP_MAX_STATES else _lib.KERNEL_FAST)
+    return {_lib.KERNEL_COOP: "k_perm_coop", _lib.KERNEL_LANES: "k_perm_lanes", _lib.KERNEL_ROWS: "k_perm_rows"}.get(
+        kernel_arg, "k_perm_fast")
 
 
 def merkle_record(H, torch, device, log_leaves: int, reps: int = 5):
@@ -430,7 +432,8 @@ def main():
                     "kernel faster (DESIGN.md section 5)"}
     if not args.no_cpu_baseline:
         # checked with the kernel that was timed, whatever the sample size would make the default dispatch pick
-        timed_kernel = args.kernel or (_lib.KERNEL_COOP if n <= COOP_MAX_STATES else _lib.KERNEL_FAST)
+        timed_kernel = args.kernel or {"k_perm_lanes": _lib.KERNEL_LANES, "k_perm_rows": _lib.KERNEL_ROWS,
+                                       "k_perm_coop": _lib.KERNEL_COOP}.get(kernel_of(0, n), _lib.KERNEL_FAST)
         cb, ok = cpu_baseline_and_check(H, torch, device, args.cpu_sample, timed_kernel)
         out["cpu_baseline"] = cb
         out["parity_vs_cpu_sample"] = all_ok = all_ok and ok

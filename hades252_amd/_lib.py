@@ -23,6 +23,7 @@ KERNEL_LITERAL = 1
 KERNEL_FAST = 2
 KERNEL_COOP = 3
 KERNEL_LANES = 4
+KERNEL_ROWS = 5
 MULTI_VIRTUAL = 1
 
 # every symbol include/hades252.h declares: name -> (restype, argtypes)

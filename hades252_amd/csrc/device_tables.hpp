@@ -19,6 +19,9 @@ __device__ const CoopTables d_coop = {HADES_COOP_ROUND_INIT, HADES_COOP_FINAL_F,
 // lane-split schedule (hades_lanes.hpp): the coop schedule with plain-limb round constants + the reduction constants
 __device__ const LanesTables d_lanes = {HADES_LANES_ROUND_INIT, HADES_COOP_FINAL_F, HADES_FAST_MDS_SMALL, HADES_P29,
                                         HADES_P29, HADES_NEG_PINV29};
+// the same arithmetic under the throughput kernel's schedule: one state per 16-lane row (rows_perm)
+__device__ const LanesTables d_rows = {HADES_ROWS_ROUND_INIT, HADES_FAST_FINAL_F, HADES_FAST_MDS_SMALL, HADES_P29,
+                                        HADES_P29, HADES_NEG_PINV29};
 // trace kernel: U_r with mont(X_after_round_r, U_r) = x * 2^256
 __device__ const int32_t d_trace_u[67][16] = HADES_FAST_TRACE_U_INIT;
 // ... + D_r: the partial-round constants of words 0..3 that the shipped schedule defers (hades_fast.hpp item 5)

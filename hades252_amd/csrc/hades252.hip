@@ -70,6 +70,8 @@ static constexpr size_t kCoopMaxStates = (size_t)1 << 14;
 static constexpr size_t kLanesMaxStates = (size_t)1 << 10;
 // ... with a helper wave per three states while that still means one block per CU (256 CUs x 3)
 static constexpr size_t kLanesHelpedMaxStates = 768;
+// ... and up to one wave per SIMD with four states per wave (one per 16-lane row) beats five waves per state
+static constexpr size_t kRowsMaxStates = (size_t)1 << 12;
 
 // one parent per lane (any size, any arity, ragged levels)
 static void launch_merkle_level(int arity, const uint8_t *children, size_t n_children, uint8_t *parents, size_t n, Fr tag,
@@ -108,6 +110,21 @@ static void launch_merkle_lanes(int arity, const uint8_t *children, size_t n_chi
         default: HADES_LAUNCH_LANES(4); break;
     }
 #undef HADES_LAUNCH_LANES
+}
+
+// four parents per wave (levels of 1 025 .. 4 096 parents)
+static void launch_merkle_rows(int arity, const uint8_t *children, size_t n_children, uint8_t *parents, size_t n, Fr tag,
+                               int out_idx, const uint8_t *pad, hipStream_t s) {
+    const dim3 grid((unsigned)((n + kRowsWaves * kRowsPerWave - 1) / (kRowsWaves * kRowsPerWave))), block(kRowsWaves * kWave);
+#define HADES_LAUNCH_ROWS(A) \
+    hipLaunchKernelGGL(k_merkle_rows<A>, grid, block, 0, s, children, n_children, parents, n, tag, out_idx, pad)
+    switch (arity) {
+        case 1: HADES_LAUNCH_ROWS(1); break;
+        case 2: HADES_LAUNCH_ROWS(2); break;
+        case 3: HADES_LAUNCH_ROWS(3); break;
+        default: HADES_LAUNCH_ROWS(4); break;
+    }
+#undef HADES_LAUNCH_ROWS
 }
 
 // five waves per parent, full levels only (n_children = arity * n_parents); n_levels > 1 only for arity 2 and 4
@@ -164,6 +181,8 @@ static void launch_merkle_any(int arity, const uint8_t *children, size_t n_child
     const size_t n_parents = (n_children + arity - 1) / arity;
     if (n_parents <= kLanesMaxStates)
         launch_merkle_lanes(arity, children, n_children, parents, n_parents, tag, out_idx, pad, s);
+    else if (n_parents <= kRowsMaxStates)
+        launch_merkle_rows(arity, children, n_children, parents, n_parents, tag, out_idx, pad, s);
     else if (n_parents <= kCoopMaxStates && n_children % arity == 0)
         launch_merkle_coop(arity, children, nullptr, parents, n_parents, tag, out_idx, 1, s);
     else
@@ -219,8 +238,10 @@ int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int
     uint8_t *p = (uint8_t *)d_states;
     // small batches are latency-bound: five waves per state (hades_coop.hpp); large ones one state per lane
     if (kernel == HADES252_KERNEL_DEFAULT)
-        kernel = n_perms <= kLanesMaxStates ? HADES252_KERNEL_LANES
-                                            : (n_perms <= kCoopMaxStates ? HADES252_KERNEL_COOP : HADES252_KERNEL_FAST);
+        kernel = n_perms <= kLanesMaxStates  ? HADES252_KERNEL_LANES
+                 : n_perms <= kRowsMaxStates ? HADES252_KERNEL_ROWS
+                 : n_perms <= kCoopMaxStates ? HADES252_KERNEL_COOP
+                                             : HADES252_KERNEL_FAST;
     for (size_t off = 0; off < n_perms; off += kMaxLaunchRecords) {
         size_t n = n_perms - off < kMaxLaunchRecords ? n_perms - off : kMaxLaunchRecords;
         if (kernel == HADES252_KERNEL_LANES) {
@@ -230,6 +251,9 @@ int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int
             else
                 hipLaunchKernelGGL(k_perm_lanes<false>, dim3((unsigned)((n + kLanesWaves - 1) / kLanesWaves)),
                                    dim3(kLanesWaves * kWave), 0, s, p + off * 160, n);
+        } else if (kernel == HADES252_KERNEL_ROWS) {
+            hipLaunchKernelGGL(k_perm_rows, dim3((unsigned)((n + kRowsWaves * kRowsPerWave - 1) / (kRowsWaves * kRowsPerWave))),
+                               dim3(kRowsWaves * kWave), 0, s, p + off * 160, n);
         } else if (kernel == HADES252_KERNEL_COOP) {
             hipLaunchKernelGGL(k_perm_coop, dim3((unsigned)((n + kCoopStates - 1) / kCoopStates)), dim3(kCoopThreads), 0,
                                s, p + off * 160, n);
@@ -1020,11 +1044,11 @@ static int merkle_run(const uint8_t *leaves, size_t n_leaves, int arity, uint8_t
         const uint8_t *pad_l = pad != nullptr ? pad + (size_t)level * 32 : nullptr;
         uint8_t *dst_pp = to_a ? buf_a : buf_b;
         int fused = 1;
-        if ((arity == 2 || arity == 4) && parents > kLanesMaxStates && parents <= kCoopMaxStates && log_arity(n, arity) > 0) {
-            // fuse while the level after the last fused one is still too large for one-parent-per-wave
+        if ((arity == 2 || arity == 4) && parents > kRowsMaxStates && parents <= kCoopMaxStates && log_arity(n, arity) > 0) {
+            // fuse while the level after the last fused one is still too large for the per-row / per-wave kernels
             const int max_fused = log_arity(kCoopStates, arity) + 1;                   // 64 parents -> 1 digest
             size_t sz = parents;
-            while (fused < max_fused && sz / arity > kLanesMaxStates) {
+            while (fused < max_fused && sz / arity > kRowsMaxStates) {
                 sz /= arity;
                 fused++;
             }

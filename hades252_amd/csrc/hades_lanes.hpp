@@ -506,4 +506,101 @@ __device__ __forceinline__ void lanes_idle() {
     for (int i = 0; i < kLanesBarriers; i++) __syncthreads();
 }
 
+// ---- four permutations per wave: one state per ROW ---------------------------------------------------------------
+// For batches too large for one wave per state (more than one wave per SIMD would queue) and too small for one state per
+// lane: row s of the wave holds state s, its five words in five registers (lane k = limb k).  No word of a state ever
+// leaves its row, so there is no exchange at all; the words run through the products one after the other.  With nothing
+// idle to lift words 0..3, the schedule is the THROUGHPUT kernel's (hades252_amd/_derive.py::fast_schedule): word 4
+// comes back to the common scale with K_r -- four products per partial round, fifteen per full round -- and words 0..3
+// meet only the linear layer in the partial rounds (their constants are pushed through it, effective_constants()).
+// Tables: LanesTables with HADES_ROWS_ROUND_INIT {A[5][9] plain limbs, K[9], zeros} and the fast schedule's final factor.
+// Limb-exact Python replay with the word bounds asserted: tests/test_fast_model.py::rows_perm_model.
+struct RowsLds {                // per wave
+    uint32_t io[4][5][16];      // [state][word][limb]
+};
+
+// in: lane 5 s + w (s < 4, w < 5) holds word w of the wave's state s as a BlsScalar (other lanes ignored);
+// out: the permuted words, fully reduced, in the same lanes.
+__device__ __forceinline__ Fr rows_perm(const LanesTables *T, RowsLds &L, const Fr &in) {
+    const int lane = threadIdx.x & 63, row = lane >> 4, k = lane & 15;
+    LaneConsts K;
+#pragma unroll
+    for (int i = 0; i < kNL; i++) {
+        K.p[i] = T->p[i];
+        K.pinv[i] = T->pinv[i];
+    }
+    uint32_t cm[5][5];
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) cm[i][j] = T->mds[i][j];
+    const uint32_t pk = T->p16[k];
+    if (lane < 20) {
+        const F29 f = to_f29(in);
+        const int s_in = lane / 5, w_in = lane - 5 * s_in;
+#pragma unroll
+        for (int i = 0; i < 16; i++) L.io[s_in][w_in][i] = i < kNL ? (uint32_t)f.l[i] : 0u;
+    }
+    lanes_fence();
+    uint32_t w[5], c[5], ck;
+#pragma unroll
+    for (int j = 0; j < 5; j++) w[j] = L.io[row][j][k];
+    const uint32_t *rec = &T->round[0][0];
+    auto fetch = [&](uint32_t (&cc)[5], uint32_t &kk) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) cc[j] = rec[k < kNL ? j * kNL + k : 54];
+        kk = rec[k < kNL ? 5 * kNL + k : 54];
+    };
+    fetch(c, ck);
+    auto linear = [&]() {
+        uint32_t y[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) y[i] = lane_mds_row(cm[i], w, pk);
+#pragma unroll
+        for (int i = 0; i < 5; i++) w[i] = y[i];
+    };
+    auto full_round = [&]() {
+        rec += 64;
+        uint32_t n[5], nk;
+        fetch(n, nk);                                                // next round's constants arrive during this one
+#pragma unroll
+        for (int j = 0; j < 5; j++) w[j] = lane_sbox(K, w[j] + c[j]);
+        linear();
+#pragma unroll
+        for (int j = 0; j < 5; j++) c[j] = n[j];
+        ck = nk;
+#pragma unroll
+        for (int j = 0; j < 5; j++) asm volatile("" : "+v"(w[j]));
+    };
+    auto partial_round = [&]() {
+        rec += 64;
+        uint32_t n[5], nk;
+        fetch(n, nk);
+        const uint32_t v5 = lane_sbox(K, w[4] + c[4]);
+        w[4] = lane_mont_mul(K, v5, ck);                             // back to the common scale
+        linear();
+#pragma unroll
+        for (int j = 0; j < 5; j++) c[j] = n[j];
+        ck = nk;
+#pragma unroll
+        for (int j = 0; j < 5; j++) asm volatile("" : "+v"(w[j]));
+    };
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) full_round();
+#pragma unroll 1
+    for (int r = 4; r < 63; r++) partial_round();
+#pragma unroll 1
+    for (int r = 63; r < 67; r++) full_round();
+#pragma unroll
+    for (int j = 0; j < 5; j++) L.io[row][j][k] = w[j];
+    lanes_fence();
+    F29 f;
+    {
+        const int s_out = lane < 20 ? lane / 5 : 0, w_out = lane < 20 ? lane - 5 * s_out : 0;
+#pragma unroll
+        for (int i = 0; i < kNL; i++) f.l[i] = (int32_t)L.io[s_out][w_out][i];
+    }
+    return finalize(mont_mul_const(f, T->final_f));
+}
+
 }  // namespace hades

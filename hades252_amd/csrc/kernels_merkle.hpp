@@ -88,6 +88,27 @@ __global__ void __launch_bounds__(kLanesWaves *kWave) k_merkle_lanes(const uint8
     if (lane == out_idx) store_word(parents + rec * 32, out);
 }
 
+// One Merkle level, four parents per wave (one per row: rows_perm); ragged levels and `pad` as above.
+template <int ARITY>
+__global__ void __launch_bounds__(kRowsWaves *kWave) k_merkle_rows(const uint8_t *__restrict__ children, size_t n_children,
+                                                                   uint8_t *__restrict__ parents, size_t n_parents, Fr tag,
+                                                                   int out_idx, const uint8_t *__restrict__ pad) {
+    __shared__ RowsLds L[kRowsWaves];
+    const int wave = threadIdx.x >> 6;
+    if (((size_t)blockIdx.x * kRowsWaves + wave) * kRowsPerWave >= n_parents) return;
+    size_t rec;
+    int word;
+    const bool mine = rows_role(n_parents, rec, word);
+    Fr in = zero_word();
+    if (mine && word == 0) in = tag;
+    if (mine && word >= 1 && word <= ARITY) {
+        const size_t c = rec * ARITY + (word - 1);
+        in = c < n_children ? load_word(children + c * 32) : load_pad(pad);
+    }
+    const Fr out = rows_perm(&d_rows, L[wave], in);
+    if (mine && word == out_idx) store_word(parents + rec * 32, out);
+}
+
 // Incremental update, one level: query q names a changed LEAF indices[q]; its ancestor on this level is parent
 // p = indices[q] / span (span = ARITY^(level+1)), recomputed from the level below (already up to date) and written in
 // place.  A query whose predecessor has the same ancestor leaves it to the predecessor (sorted index lists do each

@@ -372,6 +372,31 @@ __device__ __forceinline__ bool lanes_role(LanesLds *L, size_t n, size_t &rec, W
     }
 }
 
+// ---- four states per wave, one per 16-lane row (hades_lanes.hpp::rows_perm): batches of 1 025 .. 4 096 states --------
+// One wave per SIMD up to 4 096 states (256 blocks x 4 waves x 4 states): ~71 us, between one state per wave (which
+// would queue several waves per SIMD here) and five waves per state (104 us).
+constexpr int kRowsWaves = 4, kRowsPerWave = 4;
+__device__ __forceinline__ bool rows_role(size_t n, size_t &rec, int &word) {          // false: nothing for this lane
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    const int s = lane / 5;
+    word = lane - 5 * s;
+    rec = ((size_t)blockIdx.x * kRowsWaves + wave) * kRowsPerWave + s;
+    return lane < 5 * kRowsPerWave && rec < n;
+}
+
+__global__ void __launch_bounds__(kRowsWaves *kWave) k_perm_rows(uint8_t *states, size_t n) {
+    __shared__ RowsLds L[kRowsWaves];
+    const int wave = threadIdx.x >> 6;
+    if (((size_t)blockIdx.x * kRowsWaves + wave) * kRowsPerWave >= n) return;             // (no block-wide barrier anywhere)
+    size_t rec;
+    int word;
+    const bool mine = rows_role(n, rec, word);
+    uint8_t *p = states + (mine ? rec : 0) * 160 + word * 32;
+    const Fr in = mine ? load_word(p) : zero_word();
+    const Fr out = rows_perm(&d_rows, L[wave], in);
+    if (mine) store_word(p, out);
+}
+
 // In-place permutation, one state per wave.
 template <bool HELPED>
 __global__ void __launch_bounds__(kLanesWaves *kWave) k_perm_lanes(uint8_t *states, size_t n) {

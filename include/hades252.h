@@ -61,7 +61,9 @@ extern "C" {
 #define HADES252_KERNEL_LITERAL 1 /* the reference's round structure, 1972 Montgomery products */
 #define HADES252_KERNEL_FAST 2    /* scale-tracked small-integer MDS formulation, one state per lane */
 #define HADES252_KERNEL_COOP 3    /* same arithmetic, the five words of a state on five waves: less than half the
-                                     latency, ~2/3 of the throughput; DEFAULT picks it for 1024 < n_perms <= 16384 */
+                                     latency, ~2/3 of the throughput; DEFAULT picks it for 4096 < n_perms <= 16384 */
+#define HADES252_KERNEL_ROWS 5    /* the same lane arithmetic, one state per 16-lane ROW (four per wave), the throughput
+                                     kernel's schedule: DEFAULT picks it for 1024 < n_perms <= 4096 (~71 us) */
 #define HADES252_KERNEL_LANES 4   /* one state per wave, every field element spread over a 16-lane row (products by the
                                      row, lane-parallel carries): the lowest latency for ONE permutation -- the
                                      reference's own call shape (README.md:60-61); DEFAULT picks it for n_perms <= 1024

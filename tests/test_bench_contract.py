@@ -71,5 +71,9 @@ def test_bench_reports_the_kernel_that_ran():
                  "4096", "--no-secondary"])
     assert small["config"]["kernel"] == "k_perm_coop" and small["roofline"]["kernel"] == "k_perm_coop"
     assert "valu_issue" not in small and small["roofline"]["traffic"] is None and small["parity_vs_cpu_sample"] is True
+    for per, name in ((512, "k_perm_lanes"), (3000, "k_perm_rows")):
+        tiny = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--perms-per-gpu", str(per), "--cpu-sample",
+                    "4096", "--no-secondary"])
+        assert tiny["config"]["kernel"] == name and tiny["parity_vs_cpu_sample"] is True
     mk = run([sys.executable, "bench.py", "--workload", "merkle", "--steps", "3"])
     assert mk["unit"] == "nodes/s" and mk["roofline"]["algorithmic_bytes_per_node"] == 160 and mk["value"] > 1e8

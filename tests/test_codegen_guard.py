@@ -69,7 +69,7 @@ def test_perm_fast_instruction_mix(device_asm):
 
 @pytest.mark.parametrize("needle", ["k_perm_fast", "k_sponge", "k_merkle_level_fast", "k_merkle_coop", "k_perm_coop",
                                     "k_perm_trace_fast", "k_perm_witness", "k_fr_op", "k_perm_lanes", "k_merkle_lanes",
-                                    "k_merkle_verify", "k_merkle_update", "k_wire"])
+                                    "k_merkle_verify", "k_merkle_update", "k_wire", "k_perm_rows", "k_merkle_rows"])
 def test_hot_kernels_have_no_scratch(device_asm, needle):
     _, res = device_asm
     for name in find(res, needle):

@@ -560,3 +560,43 @@ def test_lanes_tables_are_the_coop_schedule_with_plain_limbs():
     assert "{" + ", ".join("%d" % x for x in first) + "}" in text
     assert "{" + ", ".join("%d" % x for x in PINV29) + "}" in text
     assert (val(PINV29) * P + 1) % D.RP == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# k_perm_rows (hades_lanes.hpp::rows_perm): one state per 16-lane ROW, four states per wave -- the lane arithmetic above
+# under the THROUGHPUT kernel's schedule (fast_schedule: word 4 comes back to the common scale with K_r, words 0..3 meet
+# only the linear layer in the partial rounds), round constants with plain limbs
+# ------------------------------------------------------------------------------------------------------------------
+def rows_perm_model(mont_vals):
+    sch = D.fast_schedule()
+    row_of = lambda v: D.to_limbs29(v) + [0] * 7
+    st = [row_of(v) for v in mont_vals]
+    for r in range(D.ROUNDS):
+        if D.is_full_round(r):
+            nxt = [lane_sbox([u32(a + b) for a, b in zip(st[w], row_of(sch["full"][r][w]))]) for w in range(5)]
+        else:
+            a, k = sch["part"][r]
+            assert all(a[w] == 0 for w in range(4))
+            v5 = lane_sbox([u32(x + y) for x, y in zip(st[4], row_of(a[4]))])
+            nxt = st[:4] + [lane_mont_mul(v5, row_of(k))]
+        st = [lane_mds_row(D.MDS_SMALL[i], nxt) for i in range(5)]
+    return [finalize_model(x[:NL], sch["final_f"]) for x in st]
+
+
+def test_rows_model_matches_spec_oracle():
+    rng = random.Random(53)
+    cases = [[1] * 5, [0] * 5, [P - 1] * 5, [15, 1, 2, 3, 4]]
+    cases += [[rng.choice(EDGE) for _ in range(5)] for _ in range(3)]
+    cases += [[rng.randrange(P) for _ in range(5)] for _ in range(3)]
+    for vals in cases:
+        assert rows_perm_model([S.to_mont(v) for v in vals]) == [S.to_mont(v) for v in S.perm(vals)]
+
+
+def test_rows_tables_are_the_fast_schedule_with_plain_limbs():
+    text = open(os.path.join(ROOT, "hades252_amd", "csrc", "hades_constants.inc")).read()
+    assert "#define HADES_ROWS_ROUND_INIT" in text
+    sch = D.fast_schedule()
+    for r in (0, 4, 62, 66):
+        a, k = (sch["full"][r], 0) if r in sch["full"] else sch["part"][r]
+        rec = [x for v in a for x in D.to_limbs29(v)] + D.to_limbs29(k) + [0] * 10
+        assert "{" + ", ".join("%d" % x for x in rec) + "}" in text, r

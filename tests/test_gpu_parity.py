@@ -15,8 +15,8 @@ from oracle_lib import P, R, limbs_of, int_of, digest_ref  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [1, 2, 3, 4]   # HADES252_KERNEL_LITERAL, _FAST (one state per lane), _COOP (five waves per state), _LANES (one
-                         # state per wave, elements spread over 16-lane rows)
+KERNELS = [1, 2, 3, 4, 5]   # HADES252_KERNEL_LITERAL, _FAST (one state per lane), _COOP (five waves per state), _LANES (one
+                            # state per wave, elements spread over 16-lane rows), _ROWS (one state per row, four per wave)
 
 
 @pytest.fixture(scope="module")

@@ -194,12 +194,12 @@ def test_multi_workers_concurrent_with_host_calls(torch_cuda, H, oracle):
 # ---------------------------------------------------------------------------------------------
 def test_default_dispatch_across_both_thresholds(torch_cuda, H, oracle):
     torch = torch_cuda
-    for n in (1, 2, 3, 4, 5, 6, 7, 767, 768, 769, 1023, 1024, 1025, 2048, (1 << 14), (1 << 14) + 1):
+    for n in (1, 2, 3, 4, 5, 6, 7, 15, 16, 17, 767, 768, 769, 1023, 1024, 1025, 2048, 4095, 4096, 4097, (1 << 14), (1 << 14) + 1):
         inp = oracle.gen_b(11 * n, 5 * n)
         guard = np.full(40, 0xDEADBEEFCAFEF00D, dtype=np.uint64)
         exp = oracle.perm_batch(inp)
-        for kernel in (0, 4):
-            if kernel == 4 and n > 2048:
+        for kernel in (0, 4, 5):
+            if kernel in (4, 5) and n > 4097:
                 continue
             buf = to_dev(torch, np.concatenate([guard, inp, guard]))
             H.ScalarStrategy(kernel).perm(buf[40:40 + 20 * n])
@@ -215,6 +215,9 @@ def test_lanes_kernel_2pow18_vs_fast(torch_cuda, H):
     H.ScalarStrategy(2).perm(a)
     H.ScalarStrategy(4).perm(b)
     assert torch.equal(a, b)
+    c = H.gen_b(5 << 18, "cuda")
+    H.ScalarStrategy(5).perm(c)                      # one state per row
+    assert torch.equal(a, c)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -234,7 +237,7 @@ def test_merkle_single_levels_all_arities_and_kernels(torch_cuda, H, oracle, ari
     pad = oracle.gen_b(555, 1)
     dpad = to_dev(torch, pad).view(1, 4)
     for n_children in (1, arity, arity + 1, 5 * arity - 1, 64 * arity, 1024 * arity, 1024 * arity + 1, 1025 * arity - 1,
-                       5000 * arity, (1 << 14) * arity + 3, 40000 * arity - 2):
+                       4096 * arity, 4096 * arity - 1 if arity > 1 else 4095, 4096 * arity + 1, 5000 * arity, (1 << 14) * arity + 3, 40000 * arity - 2):
         ch = oracle.gen_b(17 * n_children, n_children)
         exp = oracle.merkle_level_pad(ch, arity, TAG[arity], 1, pad)
         got = to_host(H.merkle_level(to_dev(torch, ch).view(-1, 4), arity, TAG[arity], 1, pad=dpad))
