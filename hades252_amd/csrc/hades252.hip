@@ -1529,6 +1529,46 @@ int hades252_sponge_hash(const uint64_t *msgs, size_t n_msgs, size_t msg_len, co
     TRY_CALL(call, hipStreamSynchronize(pp.s_out));
     return call.finish(HADES252_OK);
 }
+// Variable-length form: the whole pool is uploaded (messages may overlap and lie anywhere in it), offsets / lengths with
+// it; ragged batches are sorted by block count on the device as hades252_sponge_hash_var_ex_dev does with scratch.
+int hades252_sponge_hash_var(const uint64_t *scalars, size_t n_scalars, const uint64_t *offsets, const uint64_t *lengths,
+                             size_t n_msgs, const uint64_t capacity_mont[4], int pad_mode, uint64_t *digests,
+                             size_t *n_bad) {
+    if (n_bad != nullptr) *n_bad = 0;
+    if (n_msgs == 0) return HADES252_OK;
+    if (digests == nullptr || capacity_mont == nullptr || offsets == nullptr || lengths == nullptr ||
+        (scalars == nullptr && n_scalars > 0) || (pad_mode != 0 && pad_mode != 1) || n_msgs > kMaxLaunchRecords ||
+        n_scalars > SIZE_MAX / 64)
+        return HADES252_ERR_INVALID_ARG;
+    int rc = check_device();
+    if (rc != HADES252_OK) return rc;
+    auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t pool_b = up16(n_scalars * 32 + 16), idx_b = up16(n_msgs * 8), dig_b = n_msgs * 32;
+    const size_t scr_b = up16(hades252_sponge_sort_scratch_bytes(n_msgs));
+    HostCall call;
+    rc = acquire_pipe(16, call.pipe);
+    if (rc != HADES252_OK) return rc;
+    call.have_pipe = true;
+    HostPipe &pp = call.pipe;
+    rc = pipe_ensure_aux(pp, pool_b + 2 * idx_b + dig_b + scr_b + 16);
+    if (rc != HADES252_OK) return call.finish(rc);
+    uint8_t *d_pool = (uint8_t *)pp.aux, *d_off = d_pool + pool_b, *d_len = d_off + idx_b, *d_dig = d_len + idx_b;
+    uint8_t *d_scr = d_dig + dig_b, *d_bad = d_scr + scr_b;
+    if (n_scalars && pin_input_for_call(scalars, n_scalars * 32)) call.registered = scalars;
+    if (n_scalars) TRY_CALL(call, hipMemcpyAsync(d_pool, scalars, n_scalars * 32, hipMemcpyHostToDevice, pp.s_k));
+    TRY_CALL(call, hipMemcpyAsync(d_off, offsets, n_msgs * 8, hipMemcpyHostToDevice, pp.s_k));
+    TRY_CALL(call, hipMemcpyAsync(d_len, lengths, n_msgs * 8, hipMemcpyHostToDevice, pp.s_k));
+    TRY_CALL(call, hipMemsetAsync(d_bad, 0, 4, pp.s_k));
+    rc = hades252_sponge_hash_var_ex_dev(d_pool, n_scalars, (const uint64_t *)d_off, (const uint64_t *)d_len, n_msgs,
+                                         capacity_mont, pad_mode, d_dig, (int *)d_bad, d_scr, scr_b, pp.s_k);
+    if (rc != HADES252_OK) return call.finish(rc);
+    int bad = 0;
+    TRY_CALL(call, hipMemcpyAsync(digests, d_dig, dig_b, hipMemcpyDeviceToHost, pp.s_k));
+    TRY_CALL(call, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, pp.s_k));
+    TRY_CALL(call, hipStreamSynchronize(pp.s_k));
+    if (n_bad != nullptr) *n_bad = (size_t)bad;
+    return call.finish(HADES252_OK);
+}
 #undef TRY_CALL
 
 }  // extern "C"

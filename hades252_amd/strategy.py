@@ -295,6 +295,21 @@ def sponge_hash_host(msgs: np.ndarray, n_msgs: int, msg_len: int, capacity_mont:
     return out
 
 
+def sponge_hash_var_host(scalars: np.ndarray, offsets: np.ndarray, lengths: np.ndarray, capacity_mont: int, pad_mode: int = 1):
+    """``hades252_sponge_hash_var``: (digests [n, 4], number of out-of-pool messages) for ragged messages in HOST memory."""
+    scalars, offsets, lengths = (_host_u64(a, "sponge_hash_var_host") for a in (scalars, offsets, lengths))
+    if scalars.size % 4 or offsets.size != lengths.size:
+        raise ValueError("sponge_hash_var_host: malformed pool / index arrays")
+    n = offsets.size
+    out = np.zeros((n, 4), dtype=np.uint64)
+    bad = ctypes.c_size_t(0)
+    check(_lib.lib().hades252_sponge_hash_var(scalars.ctypes.data_as(ctypes.c_void_p) if scalars.size else None, scalars.size // 4,
+                                              offsets.ctypes.data_as(ctypes.c_void_p), lengths.ctypes.data_as(ctypes.c_void_p),
+                                              n, _tag_arr(capacity_mont), pad_mode, out.ctypes.data_as(ctypes.c_void_p),
+                                              ctypes.byref(bad)), "sponge_hash_var_host")
+    return out, int(bad.value)
+
+
 def perm_trace(states_t, kernel: int = _lib.KERNEL_DEFAULT, out=None):
     """State after every round (round-major: result[r] is the batch after round r); the input is
     left untouched.  Witness pre-computation for the reference's GadgetStrategy

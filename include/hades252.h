@@ -138,6 +138,12 @@ int hades252_merkle_root(const uint64_t *leaves, size_t n_leaves, int arity, con
                          const uint64_t *pad, uint64_t root[4]);
 int hades252_sponge_hash(const uint64_t *msgs, size_t n_msgs, size_t msg_len, const uint64_t capacity_mont[4],
                          int pad_mode, uint64_t *digests);
+/* ... and the variable-length sponge (semantics of hades252_sponge_hash_var_ex_dev with sorting): scalars is the pool
+ * (n_scalars x 4 u64), message i = scalars[offsets[i] .. offsets[i] + lengths[i]); *n_bad (may be NULL) receives the
+ * number of messages that did not lie inside the pool (hashed as empty messages, never read). */
+int hades252_sponge_hash_var(const uint64_t *scalars, size_t n_scalars, const uint64_t *offsets, const uint64_t *lengths,
+                             size_t n_msgs, const uint64_t capacity_mont[4], int pad_mode, uint64_t *digests,
+                             size_t *n_bad);
 
 /* Per-round trace (witness pre-computation for GadgetStrategy, src/strategies/gadget.rs:41-133):
  * d_trace receives 67 batches, round-major: trace[r] (n_perms x 160 B, same AoS format) is the

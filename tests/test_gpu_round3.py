@@ -674,6 +674,20 @@ def test_host_merkle_root_and_sponge(torch_cuda, H, oracle, monkeypatch, chunk_b
             assert (got.reshape(-1) == oracle.sponge_var(np.zeros(4, dtype=np.uint64), z, z, CAP, pad)).all()
         elif n * ln <= 300000:
             assert (got.reshape(-1) == oracle.sponge(m, ln, CAP, pad)).all(), (n, ln)
+    # ragged messages in host memory (sorted on the device above 16 384 messages), one of them outside the pool
+    rng = random.Random(31)
+    for n in (1, 700, 5000, 40000):
+        lens = [rng.choice([0, 1, 3, 4, 5, 9, 17, 40]) for _ in range(n)]
+        pool = oracle.gen_b(n, sum(lens) + 8)
+        la = np.array(lens, dtype=np.uint64)
+        oa = (np.cumsum(la) - la).astype(np.uint64)
+        if n >= 700:
+            oa[5], la[5] = np.uint64(pool.size // 4 - 2), np.uint64(3)            # runs past the end of the pool
+        got, bad = H.sponge_hash_var_host(pool, oa, la, CAP, 1)
+        exp_l = la.copy()
+        if n >= 700:
+            exp_l[5] = 0
+        assert bad == (1 if n >= 700 else 0) and (got.reshape(-1) == oracle.sponge_var(pool, oa, exp_l, CAP, 1)).all(), n
     with pytest.raises(Exception):
         H.merkle_root_host(oracle.gen_b(1, 1), 4, TAG[4])                         # one leaf is not a tree
     with pytest.raises(Exception):
