@@ -153,7 +153,12 @@ static void launch_merkle_update(int arity, const uint8_t *children, size_t n_ch
     const dim3 grid((unsigned)((n_updates + per_block - 1) / per_block)), block(kLanesWaves * kWave);
 #define HADES_LAUNCH_UPDATE(A)                                                                                          \
     do {                                                                                                                \
-        if (!lanes && n_updates <= kCoopMaxStates)                                                                      \
+        if (!lanes && n_updates <= kRowsMaxStates)                                                                      \
+            hipLaunchKernelGGL(k_merkle_update_rows<A>,                                                                 \
+                               dim3((unsigned)((n_updates + kRowsWaves * kRowsPerWave - 1) / (kRowsWaves * kRowsPerWave))), \
+                               dim3(kRowsWaves * kWave), 0, s, children, n_children, parents, indices, n_updates, n_leaves, \
+                               span, tag, out_idx, pad);                                                                \
+        else if (!lanes && n_updates <= kCoopMaxStates)                                                                 \
             hipLaunchKernelGGL(k_merkle_update_coop<A>, dim3((unsigned)((n_updates + kCoopStates - 1) / kCoopStates)), \
                                dim3(kCoopThreads), 0, s, children, n_children, parents, indices, n_updates, n_leaves,   \
                                span, tag, out_idx, pad);                                                                \
@@ -883,6 +888,14 @@ static int sponge_launch(const void *d_scalars, const uint64_t *d_offsets, const
         HIP_TRY(hipGetLastError());
         return HADES252_OK;
     }
+    if (n_msgs <= kRowsMaxStates) {                     // four messages per wave, one per 16-lane row
+        hipLaunchKernelGGL(k_sponge_rows, dim3((unsigned)((n_msgs + kRowsWaves * kRowsPerWave - 1) / (kRowsWaves * kRowsPerWave))),
+                           dim3(kRowsWaves * kWave), 0, (hipStream_t)stream, (const uint8_t *)d_scalars, d_offsets, d_lengths,
+                           (uint8_t *)d_digests, n_msgs, fixed_len, fr_from_u64(capacity_mont), pad_mode, n_scalars,
+                           d_bad_count);
+        HIP_TRY(hipGetLastError());
+        return HADES252_OK;
+    }
     if (n_msgs <= kCoopMaxStates && d_order == nullptr) {           // mid-size: five waves per message
         hipLaunchKernelGGL(k_sponge_coop, dim3((unsigned)((n_msgs + kCoopStates - 1) / kCoopStates)), dim3(kCoopThreads), 0,
                            (hipStream_t)stream, (const uint8_t *)d_scalars, d_offsets, d_lengths, (uint8_t *)d_digests,
@@ -979,6 +992,14 @@ int hades252_sponge_absorb_dev(void *d_states, const void *d_blocks, size_t n_st
         else
             hipLaunchKernelGGL(k_sponge_absorb_lanes<false>, grid, block, 0, (hipStream_t)stream, (uint8_t *)d_states,
                                (const uint8_t *)d_blocks, n_states, blocks_each);
+        HIP_TRY(hipGetLastError());
+        return HADES252_OK;
+    }
+    if (n_states <= kRowsMaxStates) {
+        hipLaunchKernelGGL(k_sponge_absorb_rows,
+                           dim3((unsigned)((n_states + kRowsWaves * kRowsPerWave - 1) / (kRowsWaves * kRowsPerWave))),
+                           dim3(kRowsWaves * kWave), 0, (hipStream_t)stream, (uint8_t *)d_states, (const uint8_t *)d_blocks,
+                           n_states, blocks_each);
         HIP_TRY(hipGetLastError());
         return HADES252_OK;
     }
@@ -1226,7 +1247,11 @@ int hades252_merkle_verify_dev(const void *d_leaves, const uint64_t *d_indices, 
     (const uint8_t *)d_leaves, d_indices, (const uint8_t *)d_paths, n_queries, depth, tag, out_idx, (uint8_t *)d_roots
 #define HADES_LAUNCH_VERIFY(A)                                                                                       \
     do {                                                                                                             \
-        if (!lanes && n_queries <= kCoopMaxStates)                                                                   \
+        if (!lanes && n_queries <= kRowsMaxStates)                                                                   \
+            hipLaunchKernelGGL(k_merkle_verify_rows<A>,                                                              \
+                               dim3((unsigned)((n_queries + kRowsWaves * kRowsPerWave - 1) / (kRowsWaves * kRowsPerWave))), \
+                               dim3(kRowsWaves * kWave), 0, (hipStream_t)stream, HADES_VERIFY_ARGS);                 \
+        else if (!lanes && n_queries <= kCoopMaxStates)                                                              \
             hipLaunchKernelGGL(k_merkle_verify_coop<A>, dim3((unsigned)((n_queries + kCoopStates - 1) / kCoopStates)), \
                                dim3(kCoopThreads), 0, (hipStream_t)stream, HADES_VERIFY_ARGS);                       \
         else if (!lanes)                                                                                             \

@@ -331,6 +331,66 @@ __global__ void __launch_bounds__(kLanesWaves *kWave) k_merkle_verify_lanes(cons
     if (lane == 0) store_word(roots + q * 32, node);
 }
 
+// the same two chains with four queries per wave, one per 16-lane row (1 025 .. 4 096 queries)
+template <int ARITY>
+__global__ void __launch_bounds__(kRowsWaves *kWave) k_merkle_update_rows(const uint8_t *__restrict__ children,
+                                                                          size_t n_children, uint8_t *__restrict__ parents,
+                                                                          const uint64_t *__restrict__ indices, size_t n_updates,
+                                                                          size_t n_leaves, uint64_t span, Fr tag, int out_idx,
+                                                                          const uint8_t *__restrict__ pad) {
+    __shared__ RowsLds L[kRowsWaves];
+    const int wave = threadIdx.x >> 6;
+    if (((size_t)blockIdx.x * kRowsWaves + wave) * kRowsPerWave >= n_updates) return;
+    size_t q;
+    int word;
+    bool mine = rows_role(n_updates, q, word);
+    const UpdateWanted wanted{indices, n_leaves, span};
+    mine = mine && wanted(q);
+    const size_t parent = mine ? indices[q] / span : 0;
+    Fr in = zero_word();
+    if (mine && word == 0) in = tag;
+    if (mine && word >= 1 && word <= ARITY) in = update_child<ARITY>(children, n_children, parent, word - 1, pad);
+    const Fr out = rows_perm(&d_rows, L[wave], in);
+    if (mine && word == out_idx) store_word(parents + parent * 32, out);
+}
+
+template <int ARITY>
+__global__ void __launch_bounds__(kRowsWaves *kWave) k_merkle_verify_rows(const uint8_t *__restrict__ leaves,
+                                                                          const uint64_t *__restrict__ indices,
+                                                                          const uint8_t *__restrict__ paths, size_t n_queries,
+                                                                          int depth, Fr tag, int out_idx,
+                                                                          uint8_t *__restrict__ roots) {
+    __shared__ RowsLds L[kRowsWaves];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    if (((size_t)blockIdx.x * kRowsWaves + wave) * kRowsPerWave >= n_queries) return;
+    size_t q;
+    int word;
+    const bool mine = rows_role(n_queries, q, word);
+    uint64_t idx = mine ? indices[q] : 0;
+    const uint8_t *path = paths + (mine ? q : 0) * (size_t)depth * (ARITY - 1) * 32;
+    Fr node = mine ? load_word(leaves + q * 32) : zero_word();       // every lane of a query holds its path node
+    auto sibling = [&](int l, uint64_t at) {                         // lane 5 s + 1 + c: child c of level l, unless it is the node
+        Fr v = zero_word();
+        const int pos = (int)(at % ARITY), c = word - 1;
+        if (mine && word >= 1 && word <= ARITY && c != pos)
+            v = load_word(path + ((size_t)l * (ARITY - 1) + (c < pos ? c : c - 1)) * 32);
+        return v;
+    };
+    Fr sib = sibling(0, idx);
+    const int src = lane - word + out_idx;                           // the lane of my query that holds the digest
+#pragma unroll 1
+    for (int l = 0; l < depth; l++) {
+        const int pos = (int)(idx % ARITY);
+        idx /= ARITY;
+        const Fr in = fr_select(word == 0, tag, fr_select(word == pos + 1, node, sib));
+        if (l + 1 < depth) sib = sibling(l + 1, idx);
+        const Fr out = rows_perm(&d_rows, L[wave], in);
+#pragma unroll
+        for (int i = 0; i < 8; i++) node.l[i] = __shfl(out.l[i], src < kWave ? src : 0, kWave);
+    }
+    if (mine && word == 0) store_word(roots + q * 32, node);
+}
+
 // incremental update, one level (see k_merkle_update_fast): lane = query, wave = state word
 template <int ARITY>
 __global__ void __launch_bounds__(kCoopThreads) k_merkle_update_coop(const uint8_t *__restrict__ children, size_t n_children,

@@ -283,6 +283,67 @@ __global__ void __launch_bounds__(kCoopThreads) k_sponge_absorb_coop(uint8_t *st
     if (live) store_word(mine, st);
 }
 
+// ---- 1 025 .. 4 096 chains: four per wave, one per 16-lane row (hades_lanes.hpp::rows_perm) -----------------------------
+// No block barrier: every wave runs to the maximum block count of ITS four messages.
+__global__ void __launch_bounds__(kRowsWaves *kWave) k_sponge_rows(const uint8_t *__restrict__ scalars,
+                                                                   const uint64_t *__restrict__ offsets,
+                                                                   const uint64_t *__restrict__ lengths,
+                                                                   uint8_t *__restrict__ digests, size_t n_msgs, size_t fixed_len,
+                                                                   Fr capacity, int pad_mode, size_t n_scalars, int *bad_count) {
+    __shared__ RowsLds L[kRowsWaves];
+    const int wave = threadIdx.x >> 6;
+    if (((size_t)blockIdx.x * kRowsWaves + wave) * kRowsPerWave >= n_msgs) return;
+    size_t me;
+    int word;
+    const bool mine = rows_role(n_msgs, me, word);
+    SpongeGeom g = {0, 0, 0, false};
+    if (mine) g = sponge_geom(offsets, lengths, me, fixed_len, n_scalars, pad_mode);
+    if (g.bad && word == 0 && bad_count != nullptr) atomicAdd(bad_count, 1);
+    const uint64_t trips = wave_max_u64(g.blocks);
+    auto block_word = [&](uint64_t t) {                              // lane 5 s + 1 + k: scalar 4t + k of message s
+        Fr v = zero_word();
+        if (mine && word >= 1) {
+            const uint64_t idx = 4 * t + (uint64_t)(word - 1);
+            if (idx < g.len)
+                v = load_word(scalars + (g.off + idx) * 32);
+            else if (pad_mode == 1 && idx == g.len)
+                v = one_mont_word();
+        }
+        return v;
+    };
+    Fr st = mine && word == 0 ? capacity : zero_word();
+    Fr dig = zero_word(), nxt = block_word(0);
+#pragma unroll 1
+    for (uint64_t t = 0; t < trips; t++) {
+        if (word >= 1) st = fr_add(st, nxt);
+        nxt = block_word(t + 1);
+        st = rows_perm(&d_rows, L[wave], st);
+        if (t + 1 == g.blocks) dig = st;
+    }
+    if (mine && word == 1) store_word(digests + me * 32, dig);
+}
+
+__global__ void __launch_bounds__(kRowsWaves *kWave) k_sponge_absorb_rows(uint8_t *states, const uint8_t *__restrict__ blocks,
+                                                                          size_t n, int blocks_each) {
+    __shared__ RowsLds L[kRowsWaves];
+    const int wave = threadIdx.x >> 6;
+    if (((size_t)blockIdx.x * kRowsWaves + wave) * kRowsPerWave >= n) return;
+    size_t me;
+    int word;
+    const bool mine = rows_role(n, me, word);
+    uint8_t *p = states + (mine ? me : 0) * 160 + word * 32;
+    const uint8_t *blk = blocks + (mine ? me : 0) * (size_t)blocks_each * 128 + (word >= 1 ? word - 1 : 0) * 32;
+    Fr st = mine ? load_word(p) : zero_word();
+    Fr nxt = mine ? load_word(blk) : zero_word();
+#pragma unroll 1
+    for (int t = 0; t < blocks_each; t++) {
+        if (word >= 1) st = fr_add(st, nxt);
+        if (mine && t + 1 < blocks_each) nxt = load_word(blk + (size_t)(t + 1) * 128);
+        st = rows_perm(&d_rows, L[wave], st);
+    }
+    if (mine) store_word(p, st);
+}
+
 // ---- ragged batches: counting sort of the message indices by block count --------------------------------
 // Three small launches over scratch = {counters[kSpongeBuckets + 1] (u32), order[n_msgs] (u32)}:
 //   count: histogram of min(blocks, kSpongeBuckets - 1);  scan: exclusive prefix sums (one block);  scatter: every

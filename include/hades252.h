@@ -252,7 +252,8 @@ int hades252_merkle_open_pad_dev(const void *d_leaves, const void *d_tree, size_
 /* Batched path verification: d_roots[t] (32 B) = the root recomputed from leaf value d_leaves[t] (32 B each, query
  * order), its index d_indices[t] and its opening d_paths[t] (the layout above); the caller compares with the root it
  * trusts.  `depth` dependent permutations per query; arity 1 .. 4.  One query per lane; up to 1 024 queries one query per
- * WAVE (the low-latency form: 12 levels in 0.6 ms instead of 1.9), up to 16 384 five waves per query (1.3 ms). */
+ * WAVE (the low-latency form: 12 levels in 0.6 ms instead of 1.9), up to 4 096 four queries per wave (1.0 ms), up to 16 384 five
+ * waves per query (1.3 ms). */
 int hades252_merkle_verify_dev(const void *d_leaves, const uint64_t *d_indices, const void *d_paths, size_t n_queries,
                                int depth, int arity, const uint64_t tag_mont[4], int out_idx, void *d_roots, void *stream);
 /* Incremental update (the append / overwrite path of a Merkle-tree caller: README.md:9 names the tree, the update is the
@@ -285,8 +286,8 @@ int hades252_merkle4_root_dev(const void *d_leaves, size_t n_leaves, void *d_scr
  * entry point's parity is pinned to this repo's oracle only.
  * A sponge is a chain of dependent permutations per message: batches of up to 1 024 messages (all sponge entry points,
  * hades252_sponge_absorb_dev included) run one message per WAVE on the low-latency arithmetic, ~50 us per block -- ONE
- * long message hashes at the speed of a CPU core (52 us per block) instead of 160 us per block; up to 16 384 messages
- * run five waves per message (~105 us per block); larger batches run one message per lane (throughput). */
+ * long message hashes at the speed of a CPU core (52 us per block) instead of 160 us per block; up to 4 096 four messages per
+ * wave (~85 us per block), up to 16 384 five waves per message (~105 us); larger batches run one message per lane (throughput). */
 int hades252_sponge_hash_dev(const void *d_msgs, size_t n_msgs, size_t msg_len, const uint64_t capacity_mont[4],
                              int pad_mode, void *d_digests, void *stream);
 /* Variable-length batch: message i = d_scalars[d_offsets[i] .. d_offsets[i] + d_lengths[i]) (offsets and

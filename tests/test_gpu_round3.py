@@ -315,7 +315,8 @@ def test_merkle_verify_2pow16_queries(torch_cuda, H, oracle):
 
 
 @pytest.mark.parametrize("arity,n_leaves,n_updates", [(4, 4 ** 7 * 3, 1), (4, 4 ** 7 * 3, 300), (4, 100001, 800), (2, 2 ** 15 + 11, 1024),
-                                                      (3, 3 ** 9, 5000), (4, 4 ** 8 + 1, 20000), (2, 3, 2), (4, 5, 1)])
+                                                      (3, 3 ** 9, 5000), (4, 4 ** 8 + 1, 20000), (2, 3, 2), (4, 5, 1),
+                                                      (4, 4 ** 8 + 1, 1025), (2, 2 ** 15 + 11, 4096), (3, 3 ** 9, 4097)])
 def test_merkle_update_equals_rebuild(torch_cuda, H, oracle, arity, n_leaves, n_updates):
     """Overwrite k leaves, re-hash their ancestors only: the tree equals the oracle's tree over the new leaves -- sorted and
     shuffled index lists with repeats, out-of-range indices ignored, every kernel form (wave / helped wave / lane / whole level)."""
@@ -486,7 +487,7 @@ def test_small_batch_sponge_one_message_per_wave(torch_cuda, hades_lib, H, oracl
     rng = random.Random(5 + pad)
     pool = oracle.gen_b(1234, 3000)
     dp = to_dev(torch, pool).view(-1, 4)
-    for n in (1, 2, 3, 4, 5, 100, 767, 768, 769, 1023, 1024, 1025, 1100, 5000, 16383, 16384, 16385):
+    for n in (1, 2, 3, 4, 5, 100, 767, 768, 769, 1023, 1024, 1025, 1027, 1100, 4095, 4096, 4097, 5000, 16383, 16384, 16385):
         lens = [rng.choice([0, 1, 2, 3, 4, 5, 7, 8, 9, 13, 40]) for _ in range(n)]
         offs = [rng.randrange(0, 3000 - l + 1) for l in lens]              # anywhere in the pool: messages overlap
         la, oa = np.array(lens, dtype=np.uint64), np.array(offs, dtype=np.uint64)
@@ -500,7 +501,7 @@ def test_small_batch_sponge_one_message_per_wave(torch_cuda, hades_lib, H, oracl
     assert (to_host(H.sponge_hash_var(dp, to_dev(torch, np.array([0], dtype=np.uint64)),
                                       to_dev(torch, np.array([2999], dtype=np.uint64)), CAP, pad)) == one).all()
     # fixed length, few messages
-    for n, ln in ((1, 9), (7, 4), (770, 3), (1024, 1), (1025, 5), (16384, 2), (16385, 2)):
+    for n, ln in ((1, 9), (7, 4), (770, 3), (1024, 1), (1025, 5), (4096, 3), (4097, 3), (16384, 2), (16385, 2)):
         msgs = oracle.gen_b(n + ln, n * ln)
         e = oracle.sponge(msgs, ln, CAP, pad)
         assert (to_host(H.sponge_hash(to_dev(torch, msgs).view(-1, 4), ln, CAP, pad)) == e).all(), (n, ln)
@@ -522,7 +523,8 @@ def test_small_batch_sponge_one_message_per_wave(torch_cuda, hades_lib, H, oracl
 
 def test_small_batch_streaming_absorb(torch_cuda, H, oracle):
     torch = torch_cuda
-    for n, t in ((1, 1), (1, 40), (3, 2), (4, 3), (767, 2), (769, 2), (1024, 1), (1025, 1), (1030, 3), (16384, 1), (16385, 1)):
+    for n, t in ((1, 1), (1, 40), (3, 2), (4, 3), (767, 2), (769, 2), (1024, 1), (1025, 1), (1030, 3), (4095, 2), (4096, 1), (4097, 1),
+                 (16384, 1), (16385, 1)):
         msgs = oracle.gen_b(31 * n + t, n * t * 4)
         exp = oracle.sponge(msgs, 4 * t, CAP, 0)
         st = H.SpongeStates(n, CAP)
@@ -552,7 +554,7 @@ def test_small_batch_verify_one_query_per_wave(torch_cuda, H, oracle, arity):
         for _ in range(6):
             cur = oracle.merkle_level(cur, 1, tag, 1)
         assert (to_host(ref[:50]) == cur).all()
-        for m in (1, 3, 768, 769, 1024, 1025, 16384):
+        for m in (1, 3, 768, 769, 1024, 1025, 4096, 4097, 16384):
             assert torch.equal(H.merkle_verify(chain[:m].contiguous(), z[:m].contiguous(), e[:m].contiguous(), 1, tag, 1), ref[:m])
         return
     n_leaves = arity ** 7 + 5
@@ -568,7 +570,7 @@ def test_small_batch_verify_one_query_per_wave(torch_cuda, H, oracle, arity):
     lv = leaves[idx].contiguous()
     ref = H.merkle_verify(lv, idx, paths, arity, tag, 1)                      # 17 000 queries: one per lane
     assert bool((ref == tree[-1:]).all())
-    for m in (1, 2, 3, 4, 767, 768, 769, 1024, 1025, 5000, 16384, 16385):     # per wave / five waves per query / per lane
+    for m in (1, 2, 3, 4, 767, 768, 769, 1024, 1025, 1026, 4095, 4096, 4097, 5000, 16384, 16385):   # per wave / row / five waves / lane
         r = H.merkle_verify(lv[:m].contiguous(), idx[:m].contiguous(), paths[:m].contiguous(), arity, tag, 1)
         assert torch.equal(r, ref[:m]), m
     bad = paths[:5].clone()

@@ -283,14 +283,14 @@ def sec_sponge_var():
 def sec_small():
     print("== small batches of dependent-permutation work: one message / state / query per wave (<= 1024) vs one per lane")
     pool = H.gen_b(4 * 4096 + 8, dev)
-    for nmsg, blocks in ((1, 1000), (1, 100), (64, 100), (768, 100), (1024, 100), (1025, 100), (4096, 100), (16384, 100), (16385, 100)):
+    for nmsg, blocks in ((1, 1000), (1, 100), (64, 100), (768, 100), (1024, 100), (1025, 100), (4096, 100), (4097, 100), (16384, 100), (16385, 100)):
         ln = 4 * blocks - 1                                           # + the padding 1 = `blocks` blocks exactly
         offs = (torch.arange(nmsg, dtype=torch.int64) % 7).to(dev)
         lens = torch.full((nmsg,), ln, dtype=torch.int64, device=dev)
         dt = timed(lambda: H.sponge_hash_var(pool, offs, lens, cap, 1), reps=3)
         print("sponge: %5d message(s) x %4d blocks: %9.3f ms = %7.1f us per block  (%s)"
-              % (nmsg, blocks, dt * 1e3, dt * 1e6 / blocks, "one message per wave" if nmsg <= 1024 else ("five waves per message" if nmsg <= 16384 else "one message per lane")))
-    for n in (1, 768, 1024, 1025, 16384, 16385):
+              % (nmsg, blocks, dt * 1e3, dt * 1e6 / blocks, "one message per wave" if nmsg <= 1024 else ("four messages per wave" if nmsg <= 4096 else ("five waves per message" if nmsg <= 16384 else "one message per lane"))))
+    for n in (1, 768, 1024, 1025, 4096, 4097, 16384, 16385):
         st = H.SpongeStates(n, cap)
         blk = H.gen_b(n * 50 * 4, dev).view(n, 50, 4, 4)
         dt = timed(lambda: st.absorb(blk), reps=3)
@@ -298,7 +298,7 @@ def sec_small():
     n = 1 << 24
     leaves = H.gen_b(n, dev)
     tree = H.merkle_build(leaves, 4, tag, 1)
-    for nq in (1, 64, 768, 1024, 1025, 16384, 16385, 1 << 16):
+    for nq in (1, 64, 768, 1024, 1025, 4096, 4097, 16384, 16385, 1 << 16):
         idx = torch.randint(0, n, (nq,), dtype=torch.int64, device=dev)
         pths = H.merkle_open(leaves, tree, 4, idx)
         lv = leaves[idx].contiguous()
