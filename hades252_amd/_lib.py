@@ -53,6 +53,7 @@ SIGNATURES = {
     "hades252_stream_sync": (c_int, [c_void_p]),
     "hades252_merkle_root": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_uint64), c_int, c_void_p, c_void_p]),
     "hades252_sponge_hash": (c_int, [c_void_p, c_size_t, c_size_t, POINTER(c_uint64), c_int, c_void_p]),
+    "hades252_merkle_root_multi": (c_int, [c_void_p, c_size_t, c_int, POINTER(c_uint64), c_int, c_int, ctypes.c_uint, c_void_p]),
     "hades252_sponge_hash_var": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, POINTER(c_uint64), c_int, c_void_p,
                                          POINTER(c_size_t)]),
     "hades252_perm_trace_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -1554,6 +1554,54 @@ int hades252_sponge_hash(const uint64_t *msgs, size_t n_msgs, size_t msg_len, co
     TRY_CALL(call, hipStreamSynchronize(pp.s_out));
     return call.finish(HADES252_OK);
 }
+// The tree sharded over several devices (every GPU builds complete sub-trees, the sub-roots are hashed
+// by one more small tree; no collective, the only exchange is 32 bytes per sub-tree through host memory).  Full trees
+// only (n_leaves = arity^k): the sub-trees are the S = arity^j nodes of one level, S the smallest power of the arity that
+// is >= n_workers; worker g takes sub-trees [S g / W, S (g + 1) / W) on device g (or g % devices with HADES252_MULTI_VIRTUAL).
+int hades252_merkle_root_multi(const uint64_t *leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
+                               int n_workers, unsigned flags, uint64_t root[4]) {
+    if (flags & ~(unsigned)HADES252_MULTI_VIRTUAL) return HADES252_ERR_INVALID_ARG;
+    const int k = log_arity(n_leaves, arity);
+    if (leaves == nullptr || root == nullptr || tag_mont == nullptr || k < 1 || out_idx < 0 || out_idx >= 5)
+        return HADES252_ERR_INVALID_ARG;
+    const int avail = hades252_device_count();
+    if (avail <= 0) return HADES252_ERR_NO_DEVICE;
+    const bool virt = (flags & HADES252_MULTI_VIRTUAL) != 0;
+    if (n_workers <= 0) n_workers = avail;
+    if (n_workers > (virt ? 64 : avail)) return HADES252_ERR_INVALID_ARG;
+    size_t n_sub = 1;                                                // sub-trees: a power of the arity, each >= arity leaves
+    while (n_sub < (size_t)n_workers && n_sub * arity * arity <= n_leaves) n_sub *= arity;
+    if ((size_t)n_workers > n_sub) n_workers = (int)n_sub;
+    if (n_sub == 1) return hades252_merkle_root(leaves, n_leaves, arity, tag_mont, out_idx, nullptr, root);
+    const size_t per = n_leaves / n_sub;
+    const bool registered = pin_input_for_call(leaves, n_leaves * 32);    // once for all workers (they share pages)
+    std::vector<uint64_t> sub(n_sub * 4);
+    std::vector<int> rcs(n_workers, HADES252_OK), hip_errs(n_workers, 0);
+    std::vector<std::thread> threads;
+    for (int g = 0; g < n_workers; g++) {
+        threads.emplace_back([&, g]() {
+            hipError_t err = hipSetDevice(virt ? g % avail : g);
+            if (err != hipSuccess) {
+                rcs[g] = HADES252_ERR_HIP;
+                hip_errs[g] = (int)err;
+                return;
+            }
+            const size_t b = n_sub * (size_t)g / n_workers, e = n_sub * (size_t)(g + 1) / n_workers;
+            for (size_t t = b; t < e && rcs[g] == HADES252_OK; t++)
+                rcs[g] = hades252_merkle_root(leaves + t * per * 4, per, arity, tag_mont, out_idx, nullptr, &sub[t * 4]);
+            hip_errs[g] = tl_last_hip_error;
+        });
+    }
+    for (auto &t : threads) t.join();
+    if (registered) (void)hipHostUnregister(const_cast<uint64_t *>(leaves));
+    for (int g = 0; g < n_workers; g++)
+        if (rcs[g] != HADES252_OK) {
+            tl_last_hip_error = hip_errs[g];
+            return rcs[g];
+        }
+    return hades252_merkle_root(sub.data(), n_sub, arity, tag_mont, out_idx, nullptr, root);
+}
+
 // Variable-length form: the whole pool is uploaded (messages may overlap and lie anywhere in it), offsets / lengths with
 // it; ragged batches are sorted by block count on the device as hades252_sponge_hash_var_ex_dev does with scratch.
 int hades252_sponge_hash_var(const uint64_t *scalars, size_t n_scalars, const uint64_t *offsets, const uint64_t *lengths,

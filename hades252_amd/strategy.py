@@ -283,6 +283,18 @@ def merkle_root_host(leaves: np.ndarray, arity: int, tag_mont: int, out_idx: int
     return root
 
 
+def merkle_root_multi(leaves: np.ndarray, arity: int, tag_mont: int, out_idx: int = 1, n_workers: int = 0, virtual: bool = False):
+    """``hades252_merkle_root_multi``: the root of a FULL tree (arity^k leaves in host memory), sub-trees sharded over
+    n_workers devices (0 = all visible); ``virtual``: worker g on device g % device_count."""
+    leaves = _host_u64(leaves, "merkle_root_multi")
+    root = np.zeros(4, dtype=np.uint64)
+    check(_lib.lib().hades252_merkle_root_multi(leaves.ctypes.data_as(ctypes.c_void_p), leaves.size // 4, arity,
+                                                _tag_arr(tag_mont), out_idx, n_workers,
+                                                _lib.MULTI_VIRTUAL if virtual else 0, root.ctypes.data_as(ctypes.c_void_p)),
+          "merkle_root_multi")
+    return root
+
+
 def sponge_hash_host(msgs: np.ndarray, n_msgs: int, msg_len: int, capacity_mont: int, pad_mode: int = 1) -> np.ndarray:
     """``hades252_sponge_hash``: digests [n_msgs, 4] of n_msgs fixed-length messages held in HOST memory."""
     msgs = _host_u64(msgs, "sponge_hash_host")

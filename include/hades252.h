@@ -138,6 +138,11 @@ int hades252_merkle_root(const uint64_t *leaves, size_t n_leaves, int arity, con
                          const uint64_t *pad, uint64_t root[4]);
 int hades252_sponge_hash(const uint64_t *msgs, size_t n_msgs, size_t msg_len, const uint64_t capacity_mont[4],
                          int pad_mode, uint64_t *digests);
+/* The same root with the sub-trees of a FULL tree (n_leaves = arity^k) sharded over n_workers devices (0 = all), no
+ * collective: worker g builds its complete sub-trees on device g, the sub-roots (32 B each) meet in host memory and one
+ * more small tree finishes.  flags as hades252_perm_batch_multi_ex. */
+int hades252_merkle_root_multi(const uint64_t *leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
+                               int n_workers, unsigned flags, uint64_t root[4]);
 /* ... and the variable-length sponge (semantics of hades252_sponge_hash_var_ex_dev with sorting): scalars is the pool
  * (n_scalars x 4 u64), message i = scalars[offsets[i] .. offsets[i] + lengths[i]); *n_bad (may be NULL) receives the
  * number of messages that did not lie inside the pool (hashed as empty messages, never read). */

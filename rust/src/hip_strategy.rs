@@ -33,6 +33,8 @@ extern "C" {
     /// include/hades252.h: the callers of `perm` on host memory -- leaves / messages in, 32 bytes per tree / message out.
     fn hades252_merkle_root(leaves: *const u64, n_leaves: usize, arity: i32, tag_mont: *const u64, out_idx: i32,
                             pad: *const u64, root: *mut u64) -> i32;
+    fn hades252_merkle_root_multi(leaves: *const u64, n_leaves: usize, arity: i32, tag_mont: *const u64, out_idx: i32,
+                                  n_workers: i32, flags: u32, root: *mut u64) -> i32;
     fn hades252_sponge_hash(msgs: *const u64, n_msgs: usize, msg_len: usize, capacity_mont: *const u64, pad_mode: i32,
                             digests: *mut u64) -> i32;
     fn hades252_strerror(code: i32) -> *const core::ffi::c_char;
@@ -125,6 +127,17 @@ impl HipStrategy {
             hades252_merkle_root(leaves.as_ptr() as *const u64, leaves.len(), arity as i32, tag as *const BlsScalar as *const u64,
                                  out_idx as i32, pad.map_or(core::ptr::null(), |p| p.as_ptr() as *const u64),
                                  &mut root as *mut BlsScalar as *mut u64)
+        });
+        root
+    }
+
+    /// The same root for a FULL tree (`arity^k` leaves) with the sub-trees sharded over `self.devices` GPUs (0 = all).
+    pub fn merkle_root_sharded(&self, leaves: &[BlsScalar], arity: usize, tag: &BlsScalar, out_idx: usize) -> BlsScalar {
+        let mut root = BlsScalar::zero();
+        Self::check(unsafe {
+            hades252_merkle_root_multi(leaves.as_ptr() as *const u64, leaves.len(), arity as i32,
+                                       tag as *const BlsScalar as *const u64, out_idx as i32, self.devices, 0,
+                                       &mut root as *mut BlsScalar as *mut u64)
         });
         root
     }

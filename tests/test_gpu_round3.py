@@ -714,3 +714,22 @@ def test_device_memory_helpers_without_torch_allocations(hades_lib, oracle):
     assert hades_lib.hades252_dev_alloc(None, 16) == -1 and hades_lib.hades252_dev_alloc(ctypes.byref(d), 0) == -1
     assert hades_lib.hades252_dev_upload(None, inp.ctypes.data_as(ctypes.c_void_p), 16, None) == -1
     assert hades_lib.hades252_stream_sync(None) == 0
+
+
+@pytest.mark.parametrize("workers", [1, 2, 3, 8, 16, 64])
+def test_merkle_root_multi_workers_on_one_device(torch_cuda, hades_lib, H, oracle, workers):
+    """The sub-tree sharding of SURVEY 8(e) behind the C ABI, with more workers than devices: the hipSetDevice threads, the
+    sub-tree arithmetic (worker counts that are no power of the arity, more workers than sub-trees) and the final small tree."""
+    for arity, k in ((4, 7), (2, 12), (3, 6), (4, 1), (2, 2)):
+        n = arity ** k
+        lv = oracle.gen_b(100 + n, n)
+        exp = H.merkle_root_host(lv, arity, TAG[arity])
+        assert (H.merkle_root_multi(lv, arity, TAG[arity], 1, workers, virtual=True) == exp).all(), (arity, k, workers)
+    big = oracle.gen_b(5, 4 ** 10)                                  # >= 8 MiB: page-locked once for all workers
+    assert (H.merkle_root_multi(big, 4, TAG[4], 3, workers, virtual=True) == H.merkle_root_host(big, 4, TAG[4], 3)).all()
+    with pytest.raises(Exception):
+        H.merkle_root_multi(oracle.gen_b(1, 100), 4, TAG[4], 1, workers, virtual=True)        # not a full tree
+    ndev = hades_lib.hades252_device_count()
+    if workers > ndev:
+        with pytest.raises(Exception):
+            H.merkle_root_multi(oracle.gen_b(1, 64), 4, TAG[4], 1, workers)                   # real devices only
