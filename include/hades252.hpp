@@ -141,5 +141,42 @@ public:
     std::size_t len() const { return len_; }          // scalars: WIDTH per state
 };
 
+// Device memory through the library alone (hades252_dev_alloc / _upload / _download): a caller that does not link HIP
+// keeps its data resident and feeds the `DeviceStates` of the strategy above.  Movable, frees on destruction.
+class DeviceBuffer {
+    void *p_ = nullptr;
+    std::size_t bytes_ = 0;
+
+public:
+    explicit DeviceBuffer(std::size_t bytes) : bytes_(bytes) { check(hades252_dev_alloc(&p_, bytes ? bytes : 16), "dev_alloc"); }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    DeviceBuffer(DeviceBuffer &&o) noexcept : p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; o.bytes_ = 0; }
+    ~DeviceBuffer() { if (p_) (void)hades252_dev_free(p_); }
+    void *ptr() const { return p_; }
+    std::size_t bytes() const { return bytes_; }
+    void upload(const void *host, std::size_t bytes, void *stream = nullptr) { check(hades252_dev_upload(p_, host, bytes, stream), "dev_upload"); }
+    void download(void *host, std::size_t bytes, void *stream = nullptr) const {
+        check(hades252_dev_download(host, p_, bytes, stream), "dev_download");
+        check(hades252_stream_sync(stream), "stream_sync");
+    }
+};
+
+// The callers of `perm` on host memory (dusk-poseidon's node and sponge shapes, README.md:9; tag / out_idx / capacity /
+// padding are that crate's convention and parameters here).
+inline BlsScalar merkle_root(const BlsScalar *leaves, std::size_t n_leaves, int arity, const BlsScalar &tag, int out_idx = 1,
+                             const BlsScalar *pad = nullptr) {
+    BlsScalar root{};
+    check(hades252_merkle_root(reinterpret_cast<const std::uint64_t *>(leaves), n_leaves, arity, tag.limbs, out_idx,
+                               reinterpret_cast<const std::uint64_t *>(pad), root.limbs), "merkle_root");
+    return root;
+}
+
+inline void sponge_hash(const BlsScalar *msgs, std::size_t n_msgs, std::size_t msg_len, const BlsScalar &capacity, bool pad_one,
+                        BlsScalar *digests) {
+    check(hades252_sponge_hash(reinterpret_cast<const std::uint64_t *>(msgs), n_msgs, msg_len, capacity.limbs, pad_one ? 1 : 0,
+                               reinterpret_cast<std::uint64_t *>(digests)), "sponge_hash");
+}
+
 }  // namespace dusk_hades
 #endif

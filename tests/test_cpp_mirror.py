@@ -38,3 +38,4 @@ def test_readme_example_runs(hades_lib):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "known answer perm([17;5])[0]: ok" in r.stdout
     assert "len != k*WIDTH rejected" in r.stdout
+    assert "merkle_root / DeviceBuffer / sponge_hash against perm: ok" in r.stdout
