@@ -57,9 +57,7 @@ PEAK_CLOCK_HZ = 2.4e9
 # (MI355X_MICROARCH.md).  IDEAL peak = one 64-bit op per SIMD per 4 cycles at the 2.4 GHz peak clock.
 VALU_IDEAL_G_WI = N_SIMD * PEAK_CLOCK_HZ / 4 / 1e9  # 614.4 G 64-bit wave-instr/s
 MERKLE_BYTES_PER_NODE = 160        # 4 x 32 B children in + 32 B digest out
-LANES_MAX_STATES = 1 << 10         # hades252.hip kLanesMaxStates / kRowsMaxStates: one state per wave / per 16-lane row
-ROWS_MAX_STATES = 1 << 12
-COOP_MAX_STATES = 1 << 14          # hades252.hip kCoopMaxStates: DEFAULT dispatch picks the five-waves kernel up to here
+CPU_SINGLE_THREAD_SECONDS = 2.5    # every CPU leg >= 2 s
 
 
 def usable_cores() -> int:
@@ -86,8 +84,11 @@ def cpu_baseline_and_check(H, torch, device, n_sample: int, kernel: int):
     orc = oracle_lib.load()
     cores = usable_cores()
     inp = orc.gen_b(0, 5 * n_sample)
-    # single thread on a smaller slice, all cores on the whole sample
-    n1 = max(1024, n_sample // 64)
+    # single thread on a slice sized for >= 2 s (calibrated on 2 048 permutations), all cores on the whole sample
+    t0 = time.perf_counter()
+    orc.perm_batch(inp[:20 * 2048], 1)
+    rate = 2048 / (time.perf_counter() - t0)
+    n1 = int(min(n_sample, max(4096, rate * CPU_SINGLE_THREAD_SECONDS)))
     t0 = time.perf_counter()
     orc.perm_batch(inp[:20 * n1], 1)
     t1 = time.perf_counter() - t0
@@ -104,6 +105,8 @@ def cpu_baseline_and_check(H, torch, device, n_sample: int, kernel: int):
         "sample": "first %d permutations of the same generator-B workload, %d threads "
                   "(C restatement of the reference CPU path, gcc -O3 -march=x86-64-v3)" % (n_sample, cores),
         "single_thread_value": n1 / t1,
+        "single_thread_sample": "first %d permutations of the same workload, one thread, %.2f s" % (n1, t1),
+        "all_cores_seconds": tall,
     }, ok
 
 
@@ -180,15 +183,21 @@ def launch_ranks(args) -> int:
 
 
 def kernel_of(kernel_arg: int, n: int) -> str:
-    """The kernel `hades252_perm_batch_dev_ex(.., kernel)` launches for n states (same rule as the C dispatch)."""
-    from hades252_amd import _lib
-    if kernel_arg == _lib.KERNEL_LITERAL:
-        return "k_states_literal"
-    if kernel_arg == _lib.KERNEL_DEFAULT:                                  # hades252_perm_batch_dev_ex's own rule
-        kernel_arg = (_lib.KERNEL_LANES if n <= LANES_MAX_STATES else _lib.KERNEL_ROWS if n <= ROWS_MAX_STATES
-                      else _lib.KERNEL_COOP if n <= COOP_MAX_STATES else _lib.KERNEL_FAST)
-    return {_lib.KERNEL_COOP: "k_perm_coop", _lib.KERNEL_LANES: "k_perm_lanes", _lib.KERNEL_ROWS: "k_perm_rows"}.get(
-        kernel_arg, "k_perm_fast")
+    """The kernel `hades252_perm_batch_dev_ex(.., kernel)` launches for n states: asked of the library, whose dispatch
+    rule lives in one place (`hades252_kernel_name` / `hades252_kernel_for`, include/hades252.h)."""
+    from hades252_amd import strategy as H
+    return H.kernel_name(kernel_arg, n)
+
+
+def golden_merkle_root(n_leaves: int):
+    """The CPU oracle's committed root of the arity-4 tree over the first n_leaves generator-B leaves (tag 15, word 1):
+    tests/golden/kat.json `merkle4_full_size`, written by tools/gen_constants.py.  None if that size is not pinned."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
+            rec = json.load(f)["merkle4_full_size"].get(str(n_leaves))
+        return int(rec["root"], 16) if rec else None
+    except Exception:
+        return None
 
 
 def merkle_record(H, torch, device, log_leaves: int, reps: int = 5):
@@ -212,10 +221,15 @@ def merkle_record(H, torch, device, log_leaves: int, reps: int = 5):
     med = sorted(ms)[len(ms) // 2]
     nodes = (n - 1) // 3
     ach = MERKLE_BYTES_PER_NODE * nodes / (med * 1e-3) / 1e9
+    root_hex = "".join("%016x" % (int(v) & 0xFFFFFFFFFFFFFFFF) for v in reversed(root.cpu().tolist()))
+    gold = golden_merkle_root(n)
     return {"workload": "arity-4 Poseidon Merkle tree over 2^%d leaves in HBM, root only (BASELINE configs[3]; tag 15, "
                         "digest word 1: external convention, parameters)" % log_leaves,
             "tree_ms": med, "tree_ms_all": ms, "nodes": nodes, "nodes_per_s": nodes / (med * 1e-3),
-            "root": "".join("%016x" % (int(v) & 0xFFFFFFFFFFFFFFFF) for v in reversed(root.cpu().tolist())),
+            "root": root_hex,
+            # the root of the LAST timed build against the CPU oracle's committed root of the same tree
+            "root_matches_golden": None if gold is None else int(root_hex, 16) == gold,
+            "golden": "tests/golden/kat.json merkle4_full_size (C oracle, %d permutations)" % nodes,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_node": MERKLE_BYTES_PER_NODE}}, leaves
 
@@ -334,7 +348,12 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
-        sharding.init_process_group(args.dist_backend)
+        try:
+            sharding.init_process_group(args.dist_backend)
+        except Exception as e:                     # no silent fallback, no re-exec: say why and leave with a failure
+            print("bench.py: rank %d: init_process_group(%r) failed: %r" % (rank, args.dist_backend, e), file=sys.stderr,
+                  flush=True)
+            raise SystemExit(3)
 
     if args.workload == "merkle":
         return bench_merkle(args, H, torch, device, sharding, rank, world)
@@ -432,8 +451,7 @@ def main():
                     "kernel faster (DESIGN.md section 5)"}
     if not args.no_cpu_baseline:
         # checked with the kernel that was timed, whatever the sample size would make the default dispatch pick
-        timed_kernel = args.kernel or {"k_perm_lanes": _lib.KERNEL_LANES, "k_perm_rows": _lib.KERNEL_ROWS,
-                                       "k_perm_coop": _lib.KERNEL_COOP}.get(kernel_of(0, n), _lib.KERNEL_FAST)
+        timed_kernel = args.kernel or H.kernel_for(n)
         cb, ok = cpu_baseline_and_check(H, torch, device, args.cpu_sample, timed_kernel)
         out["cpu_baseline"] = cb
         out["parity_vs_cpu_sample"] = all_ok = all_ok and ok
@@ -449,9 +467,14 @@ def main():
         except Exception as e:                       # secondary records never take the headline down
             sec["error"] = repr(e)
         out["secondary"] = sec
+        merkle_bad = sec.get("merkle_2p24", {}).get("root_matches_golden") is False
+    else:
+        merkle_bad = False
     print(json.dumps(out), flush=True)
     if not all_ok:
         raise SystemExit("GPU output differs from the CPU oracle")
+    if merkle_bad:                                   # ... but a WRONG tree does fail the job (after the line is out)
+        raise SystemExit("the 2^24-leaf Merkle root differs from the CPU oracle's committed root")
 
 
 def bench_merkle(args, H, torch, device, sharding, rank, world):
@@ -465,8 +488,10 @@ def bench_merkle(args, H, torch, device, sharding, rank, world):
            "value": nodes * world / (ms * 1e-3), "unit": "nodes/s", "n_gpus": world, "steps": args.steps,
            "warmup": 1, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "int64", "data": "synthetic", "config": {"workload": rec["workload"]},
-           "roofline": rec["roofline"], "root": rec["root"]}
+           "roofline": rec["roofline"], "root": rec["root"], "root_matches_golden": rec["root_matches_golden"]}
     print(json.dumps(out), flush=True)
+    if rec["root_matches_golden"] is False:
+        raise SystemExit("the Merkle root differs from the CPU oracle's committed root")
 
 
 if __name__ == "__main__":

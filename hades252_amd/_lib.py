@@ -33,6 +33,12 @@ SIGNATURES = {
     "hades252_strerror": (c_char_p, [c_int]),
     "hades252_last_hip_error": (c_int, []),
     "hades252_version": (c_char_p, []),
+    "hades252_kernel_for": (c_int, [c_size_t]),
+    "hades252_chain_form_for": (c_int, [c_size_t]),
+    "hades252_kernel_name": (c_char_p, [c_int, c_size_t]),
+    "hades252_trim": (c_int, []),
+    "hades252_pool_bytes": (c_size_t, []),
+    "hades252_fault_inject": (c_int, [c_char_p]),
     "hades252_perm_batch": (c_int, [c_void_p, c_size_t]),
     "hades252_perm_batch_bytes": (c_int, [c_void_p, c_size_t]),
     "hades252_perm_batch_dev": (c_int, [c_void_p, c_size_t, c_void_p]),

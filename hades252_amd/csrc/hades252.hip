@@ -6,6 +6,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <pthread.h>
+#include <sched.h>
+
+#include <atomic>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -42,6 +46,41 @@ static thread_local int tl_last_hip_error = 0;
             return HADES252_ERR_HIP;                 \
         }                                            \
     } while (0)
+
+// ---- fault injection (test hook, include/hades252.h: hades252_fault_inject / HADES252_FAIL_AT) -----------------------
+// F(site, call): the call, unless the hook is armed for `site` and this is its nth occurrence -- then the error the
+// runtime would have returned.  Disarmed: one relaxed load and a compare.
+enum FaultSite { F_NONE = -1, F_MALLOC, F_HOSTMALLOC, F_HOSTREGISTER, F_MEMCPY, F_STREAMCREATE, F_EVENTCREATE, F_SYNC,
+                 F_WORKER, F_N_SITES };
+static const char *const kFaultNames[F_N_SITES] = {"malloc", "hostmalloc", "hostregister", "memcpy", "streamcreate",
+                                                   "eventcreate", "sync", "worker"};
+static std::atomic<int> g_fault_site{F_NONE};
+static std::atomic<long> g_fault_nth{0};
+static int fault_arm(const char *spec) {
+    if (spec == nullptr || spec[0] == 0) {
+        g_fault_site.store(F_NONE);
+        return HADES252_OK;
+    }
+    const char *colon = strchr(spec, ':');
+    const size_t len = colon ? (size_t)(colon - spec) : strlen(spec);
+    const long nth = colon ? strtol(colon + 1, nullptr, 10) : 1;
+    for (int i = 0; i < F_N_SITES; i++)
+        if (strlen(kFaultNames[i]) == len && strncmp(kFaultNames[i], spec, len) == 0 && nth >= 1) {
+            g_fault_site.store(F_NONE);
+            g_fault_nth.store(nth);
+            g_fault_site.store(i);
+            return HADES252_OK;
+        }
+    return HADES252_ERR_INVALID_ARG;
+}
+static const int g_fault_env = fault_arm(getenv("HADES252_FAIL_AT"));      // at load time
+static inline bool fault_hit(int site) {
+    if (g_fault_site.load(std::memory_order_relaxed) != site) return false;
+    if (g_fault_nth.fetch_sub(1) != 1) return false;
+    g_fault_site.store(F_NONE);                                             // fires once
+    return true;
+}
+#define F(site, call) (fault_hit(site) ? (site == F_MALLOC || site == F_HOSTMALLOC ? hipErrorOutOfMemory : hipErrorUnknown) : (call))
 
 // device buffers are moved with 16-byte vector loads/stores
 static inline bool misaligned(const void *p) { return ((uintptr_t)p & 15u) != 0; }
@@ -194,6 +233,14 @@ static void launch_merkle_any(int arity, const uint8_t *children, size_t n_child
         launch_merkle_level(arity, children, n_children, parents, n_parents, tag, out_idx, pad, s);
 }
 
+// The size rule of the default dispatch, in one place (exported: hades252_kernel_for / hades252_chain_form_for).
+static inline int kernel_for(size_t n) {
+    return n <= kLanesMaxStates  ? HADES252_KERNEL_LANES
+           : n <= kRowsMaxStates ? HADES252_KERNEL_ROWS
+           : n <= kCoopMaxStates ? HADES252_KERNEL_COOP
+                                 : HADES252_KERNEL_FAST;
+}
+
 static int check_device() {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -242,11 +289,7 @@ int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int
     hipStream_t s = (hipStream_t)stream;
     uint8_t *p = (uint8_t *)d_states;
     // small batches are latency-bound: five waves per state (hades_coop.hpp); large ones one state per lane
-    if (kernel == HADES252_KERNEL_DEFAULT)
-        kernel = n_perms <= kLanesMaxStates  ? HADES252_KERNEL_LANES
-                 : n_perms <= kRowsMaxStates ? HADES252_KERNEL_ROWS
-                 : n_perms <= kCoopMaxStates ? HADES252_KERNEL_COOP
-                                             : HADES252_KERNEL_FAST;
+    if (kernel == HADES252_KERNEL_DEFAULT) kernel = kernel_for(n_perms);
     for (size_t off = 0; off < n_perms; off += kMaxLaunchRecords) {
         size_t n = n_perms - off < kMaxLaunchRecords ? n_perms - off : kMaxLaunchRecords;
         if (kernel == HADES252_KERNEL_LANES) {
@@ -279,6 +322,22 @@ int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int
 int hades252_perm_batch_dev(void *d_states, size_t n_perms, void *stream) {
     return hades252_perm_batch_dev_ex(d_states, n_perms, stream, HADES252_KERNEL_DEFAULT);
 }
+
+int hades252_kernel_for(size_t n_perms) { return kernel_for(n_perms); }
+int hades252_chain_form_for(size_t n_chains) { return kernel_for(n_chains); }
+const char *hades252_kernel_name(int kernel, size_t n_perms) {
+    if (kernel == HADES252_KERNEL_DEFAULT) kernel = kernel_for(n_perms);
+    switch (kernel) {
+        case HADES252_KERNEL_LITERAL: return "k_states_literal";
+        case HADES252_KERNEL_FAST: return "k_perm_fast";
+        case HADES252_KERNEL_COOP: return "k_perm_coop";
+        case HADES252_KERNEL_LANES: return "k_perm_lanes";
+        case HADES252_KERNEL_ROWS: return "k_perm_rows";
+        default: return nullptr;
+    }
+}
+
+int hades252_fault_inject(const char *spec) { return fault_arm(spec); }
 
 // ---- page-locked host memory --------------------------------------------------------------------
 // The reference's caller owns a `&mut [BlsScalar]` in ordinary (pageable) memory (src/strategies.rs:140).  DMA needs
@@ -371,9 +430,13 @@ int hades252_host_is_pinned(const void *p, size_t bytes) {
 // A pooled "pipe" per concurrent host call: three streams (host->device copies, kernels, device->host copies),
 // kPipeSlots chunk buffers in device memory and the events that chain them, so that a call pays neither hipMalloc /
 // hipFree nor stream / event creation (about 1 ms together) -- the reference's callers issue many small calls.
-// Pipes are created on demand, handed out exclusively and returned; the pool is bounded by the peak number of
-// concurrent calls and by kPipeSlots x 40 MiB of device memory per pipe.
+// Pipes are created on demand, handed out exclusively and returned.  The pool is bounded per device: at most
+// kPoolMaxPipes pipes and at most pool_max_bytes() of device memory (chunk buffers: kPipeSlots x up to 40 MiB per pipe;
+// the arena of the one-shot Merkle / sponge calls: whatever the largest call needed) -- release_pipe() strips a
+// returning pipe of its arena, then of its chunk buffers, when keeping them would exceed the budget, and destroys it
+// when the device already has kPoolMaxPipes; hades252_trim() empties the pool.
 constexpr int kPipeSlots = 6;
+constexpr int kPoolMaxPipes = 16;
 struct HostPipe {
     int device = -1;
     hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
@@ -407,9 +470,52 @@ static void destroy_pipe(HostPipe &p) {
     p = HostPipe();
 }
 
-static void release_pipe(const HostPipe &p) {
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_pool.push_back(p);
+static size_t pool_max_bytes() {
+    static const size_t v = []() -> size_t {
+        const char *e = getenv("HADES252_POOL_MAX_BYTES");
+        return e ? (size_t)strtoull(e, nullptr, 0) : (size_t)1 << 30;
+    }();
+    return v;
+}
+static inline size_t pipe_bytes(const HostPipe &p) { return p.slot_cap * kPipeSlots + p.aux_cap; }
+
+// A pipe that saw a failure is never pooled (its streams may hold a sticky error): pass failed = true.
+static void release_pipe(HostPipe p, bool failed = false) {
+    if (failed) {
+        destroy_pipe(p);
+        return;
+    }
+    void *free_aux = nullptr, *free_buf = nullptr;
+    bool destroy = false;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t held = 0;
+        int count = 0;
+        for (const HostPipe &q : g_pool)
+            if (q.device == p.device) {
+                held += pipe_bytes(q);
+                count++;
+            }
+        if (count >= kPoolMaxPipes) {
+            destroy = true;
+        } else {
+            if (held + pipe_bytes(p) > pool_max_bytes() && p.aux) {            // the arena goes first ...
+                free_aux = p.aux;
+                p.aux = nullptr;
+                p.aux_cap = 0;
+            }
+            if (held + pipe_bytes(p) > pool_max_bytes() && p.buf) {            // ... then the chunk buffers
+                free_buf = p.buf;
+                p.buf = nullptr;
+                p.slot_cap = 0;
+            }
+            g_pool.push_back(p);
+        }
+    }
+    if (destroy) destroy_pipe(p);
+    if (free_aux) (void)hipFree(free_aux);
+    if (free_buf) (void)hipFree(free_buf);
+    if (free_aux || free_buf) (void)hipGetLastError();
 }
 
 // slot_bytes == 0: a small call (needs the page-locked staging buffer, no device buffer)
@@ -449,30 +555,54 @@ static int acquire_pipe(size_t slot_bytes, HostPipe &out) {
     hipError_t e = hipSuccess;
     if (p.device < 0) {
         p.device = dev;
-        if ((e = hipStreamCreateWithFlags(&p.s_in, hipStreamNonBlocking)) != hipSuccess) return fail(e);
-        if ((e = hipStreamCreateWithFlags(&p.s_k, hipStreamNonBlocking)) != hipSuccess) return fail(e);
-        if ((e = hipStreamCreateWithFlags(&p.s_out, hipStreamNonBlocking)) != hipSuccess) return fail(e);
+        if ((e = F(F_STREAMCREATE, hipStreamCreateWithFlags(&p.s_in, hipStreamNonBlocking))) != hipSuccess) return fail(e);
+        if ((e = F(F_STREAMCREATE, hipStreamCreateWithFlags(&p.s_k, hipStreamNonBlocking))) != hipSuccess) return fail(e);
+        if ((e = F(F_STREAMCREATE, hipStreamCreateWithFlags(&p.s_out, hipStreamNonBlocking))) != hipSuccess) return fail(e);
         for (int i = 0; i < kPipeSlots; i++) {
-            if ((e = hipEventCreateWithFlags(&p.in_done[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
-            if ((e = hipEventCreateWithFlags(&p.k_done[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
-            if ((e = hipEventCreateWithFlags(&p.out_done[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
+            if ((e = F(F_EVENTCREATE, hipEventCreateWithFlags(&p.in_done[i], hipEventDisableTiming))) != hipSuccess) return fail(e);
+            if ((e = F(F_EVENTCREATE, hipEventCreateWithFlags(&p.k_done[i], hipEventDisableTiming))) != hipSuccess) return fail(e);
+            if ((e = F(F_EVENTCREATE, hipEventCreateWithFlags(&p.out_done[i], hipEventDisableTiming))) != hipSuccess) return fail(e);
         }
     }
     if (slot_bytes == 0 && p.pinned_dev == nullptr) {
         if (p.pinned) (void)hipHostFree(p.pinned);
         p.pinned = nullptr;
-        if ((e = hipHostMalloc(&p.pinned, kPinnedStates * 160, hipHostMallocMapped)) != hipSuccess) return fail(e);
+        if ((e = F(F_HOSTMALLOC, hipHostMalloc(&p.pinned, kPinnedStates * 160, hipHostMallocMapped))) != hipSuccess) return fail(e);
         if ((e = hipHostGetDevicePointer(&p.pinned_dev, p.pinned, 0)) != hipSuccess) return fail(e);
     }
     if (p.slot_cap < slot_bytes) {
         if (p.buf) (void)hipFree(p.buf);
         p.buf = nullptr;
         p.slot_cap = 0;
-        if ((e = hipMalloc(&p.buf, slot_bytes * kPipeSlots)) != hipSuccess) return fail(e);
+        if ((e = F(F_MALLOC, hipMalloc(&p.buf, slot_bytes * kPipeSlots))) != hipSuccess) return fail(e);
         p.slot_cap = slot_bytes;
     }
     out = p;
     return HADES252_OK;
+}
+
+int hades252_trim(void) {
+    std::vector<HostPipe> victims;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        victims.swap(g_pool);
+    }
+    int cur = -1;
+    if (!victims.empty() && hipGetDevice(&cur) != hipSuccess) cur = -1;
+    for (HostPipe &p : victims) {
+        (void)hipSetDevice(p.device);
+        destroy_pipe(p);
+    }
+    if (cur >= 0) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
+    return HADES252_OK;
+}
+
+size_t hades252_pool_bytes(void) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    size_t total = 0;
+    for (const HostPipe &q : g_pool) total += pipe_bytes(q);
+    return total;
 }
 
 static size_t host_chunk_states(size_t n_perms) {
@@ -518,9 +648,10 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
         if (rc != HADES252_OK) return rc;
         memcpy(pipe.pinned, states, n_perms * 160);
         rc = run_kernels(pipe.pinned_dev, n_perms, pipe.s_k);
-        hipError_t e = hipStreamSynchronize(pipe.s_k);
+        hipError_t e = hipStreamSynchronize(pipe.s_k);      // always really drained, whatever the hook says
+        if (e == hipSuccess) e = F(F_SYNC, hipSuccess);
         if (rc == HADES252_OK && e == hipSuccess) memcpy(states, pipe.pinned, n_perms * 160);
-        release_pipe(pipe);                                 // only now: the staging buffer belongs to the pipe
+        release_pipe(pipe, rc != HADES252_OK || e != hipSuccess);   // only now: the staging buffer belongs to the pipe
         if (rc != HADES252_OK) return rc;
         if (e != hipSuccess) {
             tl_last_hip_error = (int)e;
@@ -540,7 +671,7 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
         (void)hipStreamSynchronize(pipe.s_k);
         (void)hipStreamSynchronize(pipe.s_out);
         (void)hipGetLastError();
-        release_pipe(pipe);
+        release_pipe(pipe, code != HADES252_OK);
         if (registered) (void)hipHostUnregister(h);
         return code;
     };
@@ -552,7 +683,7 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
         return !(e && e[0] == '0');
     }();
     if (!assume_pinned && pin_enabled && n_perms * 160 >= ((size_t)8 << 20) && !host_range_pinned(h, n_perms * 160)) {
-        if (hipHostRegister(h, n_perms * 160, hipHostRegisterDefault) == hipSuccess)
+        if (F(F_HOSTREGISTER, hipHostRegister(h, n_perms * 160, hipHostRegisterDefault)) == hipSuccess)
             registered = true;
         else
             (void)hipGetLastError();
@@ -567,11 +698,11 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
         }                                            \
     } while (0)
     if (n_chunks == 1) {
-        TRY_FIN(hipMemcpyAsync(pipe.buf, h, n_perms * 160, hipMemcpyHostToDevice, pipe.s_k));
+        TRY_FIN(F(F_MEMCPY, hipMemcpyAsync(pipe.buf, h, n_perms * 160, hipMemcpyHostToDevice, pipe.s_k)));
         rc = run_kernels(pipe.buf, n_perms, pipe.s_k);
         if (rc != HADES252_OK) return finish(rc);
-        TRY_FIN(hipMemcpyAsync(h, pipe.buf, n_perms * 160, hipMemcpyDeviceToHost, pipe.s_k));
-        TRY_FIN(hipStreamSynchronize(pipe.s_k));
+        TRY_FIN(F(F_MEMCPY, hipMemcpyAsync(h, pipe.buf, n_perms * 160, hipMemcpyDeviceToHost, pipe.s_k)));
+        TRY_FIN(F(F_SYNC, hipStreamSynchronize(pipe.s_k)));
         return finish(HADES252_OK);
     }
     // The host runs at most kPipeSlots chunks ahead of the device: it waits for the chunk that last used a slot before
@@ -582,18 +713,18 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
         const int k = (int)(c % kPipeSlots);
         const size_t off = c * chunk, n = n_perms - off < chunk ? n_perms - off : chunk;
         void *d = (uint8_t *)pipe.buf + (size_t)k * pipe.slot_cap;
-        if (c >= (size_t)kPipeSlots) TRY_FIN(hipEventSynchronize(pipe.out_done[k]));   // chunk c - kPipeSlots left slot k
-        TRY_FIN(hipMemcpyAsync(d, h + off * 160, n * 160, hipMemcpyHostToDevice, pipe.s_in));
+        if (c >= (size_t)kPipeSlots) TRY_FIN(F(F_SYNC, hipEventSynchronize(pipe.out_done[k])));   // chunk c - kPipeSlots left slot k
+        TRY_FIN(F(F_MEMCPY, hipMemcpyAsync(d, h + off * 160, n * 160, hipMemcpyHostToDevice, pipe.s_in)));
         TRY_FIN(hipEventRecord(pipe.in_done[k], pipe.s_in));
         TRY_FIN(hipStreamWaitEvent(pipe.s_k, pipe.in_done[k], 0));
         rc = run_kernels(d, n, pipe.s_k);
         if (rc != HADES252_OK) return finish(rc);
         TRY_FIN(hipEventRecord(pipe.k_done[k], pipe.s_k));
         TRY_FIN(hipStreamWaitEvent(pipe.s_out, pipe.k_done[k], 0));
-        TRY_FIN(hipMemcpyAsync(h + off * 160, d, n * 160, hipMemcpyDeviceToHost, pipe.s_out));
+        TRY_FIN(F(F_MEMCPY, hipMemcpyAsync(h + off * 160, d, n * 160, hipMemcpyDeviceToHost, pipe.s_out)));
         TRY_FIN(hipEventRecord(pipe.out_done[k], pipe.s_out));
     }
-    TRY_FIN(hipStreamSynchronize(pipe.s_out));           // the last copy-out is behind everything else
+    TRY_FIN(F(F_SYNC, hipStreamSynchronize(pipe.s_out)));   // the last copy-out is behind everything else
     TRY_FIN(hipStreamSynchronize(pipe.s_k));
     TRY_FIN(hipStreamSynchronize(pipe.s_in));
 #undef TRY_FIN
@@ -631,6 +762,48 @@ int hades252_perm_batch_bytes(uint8_t *states, size_t n_perms) {
     return perm_batch_host_on_current_device((uint64_t *)states, n_perms, true);
 }
 
+// Worker threads of the _multi entry points run on the CPUs next to their device when the kernel says which those are
+// (/sys/bus/pci/devices/<bus id>/local_cpulist): their staging copies and page-lock calls then stay on the socket the
+// GPU hangs off.  Silent no-op when the file is missing, unparsable, or disjoint from the CPUs this process may use.
+static void pin_thread_near_device(int dev) {
+    char bus[64] = {0}, path[160], line[1024];
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    for (char *c = bus; *c; c++)
+        if (*c >= 'A' && *c <= 'Z') *c = (char)(*c - 'A' + 'a');
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bus);
+    FILE *f = fopen(path, "r");
+    if (f == nullptr) return;
+    const bool got = fgets(line, sizeof(line), f) != nullptr;
+    fclose(f);
+    if (!got) return;
+    cpu_set_t allowed, want;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    CPU_ZERO(&want);
+    int n_want = 0;
+    for (char *q = line; *q;) {                                  // "0-15,32-47"
+        char *end;
+        long a = strtol(q, &end, 10);
+        if (end == q) break;
+        long b = a;
+        if (*end == '-') {
+            q = end + 1;
+            b = strtol(q, &end, 10);
+            if (end == q) return;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed)) {
+                CPU_SET((int)c, &want);
+                n_want++;
+            }
+        q = (*end == ',') ? end + 1 : end;
+        if (*end != ',' ) break;
+    }
+    if (n_want > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof(want), &want);
+}
+
 // Host batch sharded over `n_workers` host threads, worker g taking the contiguous range
 // [n g / W, n (g+1) / W) on device g -- or, with HADES252_MULTI_VIRTUAL, on device g % (visible devices), which lets a
 // box with fewer GPUs than workers run the very code an 8-GPU node runs (several workers then share a device, each
@@ -652,7 +825,7 @@ int hades252_perm_batch_multi_ex(uint64_t *states, size_t n_perms, int n_workers
     if (!pinned) {
         const char *e = getenv("HADES252_HOST_PIN");
         if (!(e && e[0] == '0') && n_perms * 160 >= ((size_t)8 << 20)) {
-            if (hipHostRegister(states, n_perms * 160, hipHostRegisterPortable) == hipSuccess)
+            if (F(F_HOSTREGISTER, hipHostRegister(states, n_perms * 160, hipHostRegisterPortable)) == hipSuccess)
                 registered = true;
             else
                 (void)hipGetLastError();
@@ -664,12 +837,13 @@ int hades252_perm_batch_multi_ex(uint64_t *states, size_t n_perms, int n_workers
     for (int g = 0; g < n_workers; g++) {
         threads.emplace_back([&, g]() {
             size_t b = n_perms * (size_t)g / n_workers, e = n_perms * (size_t)(g + 1) / n_workers;
-            hipError_t err = hipSetDevice(virt ? g % avail : g);
+            hipError_t err = F(F_WORKER, hipSetDevice(virt ? g % avail : g));
             if (err != hipSuccess) {
                 rcs[g] = HADES252_ERR_HIP;
                 hip_errs[g] = (int)err;
                 return;
             }
+            pin_thread_near_device(virt ? g % avail : g);
             // registered or pinned by the caller: skip the per-shard attempt; neither (refused / disabled): also skip
             // it -- a sub-range attempt would only repeat the refusal -- and use the pageable path
             rcs[g] = perm_batch_host_on_current_device(states + 20 * b, e - b, false, true);
@@ -1189,7 +1363,10 @@ int hades252_merkle_empty_digests_dev(int arity, int depth, const uint64_t e0_mo
         return HADES252_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     uint8_t *pad = (uint8_t *)d_pad;
-    HIP_TRY(hipMemcpyAsync(pad, e0_mont, 32, hipMemcpyHostToDevice, s));
+    // e0 travels as a kernel argument, like the tag: nothing of the caller's host memory is referenced after this
+    // call returns, so the whole sequence is graph-capturable like every other _dev entry point
+    hipLaunchKernelGGL(k_store_fr, dim3(1), dim3(kWave), 0, s, (uint32_t *)pad, fr_from_u64(e0_mont));
+    HIP_TRY(hipGetLastError());
     const Fr tag = fr_from_u64(tag_mont);
     for (int l = 0; l + 1 < depth; l++) {
         // zero children + padding = a parent whose arity children are all pad[l]
@@ -1418,16 +1595,16 @@ static int pipe_ensure_aux(HostPipe &p, size_t bytes) {
     if (p.aux) (void)hipFree(p.aux);
     p.aux = nullptr;
     p.aux_cap = 0;
-    HIP_TRY(hipMalloc(&p.aux, bytes));
+    HIP_TRY(F(F_MALLOC, hipMalloc(&p.aux, bytes)));
     p.aux_cap = bytes;
     return HADES252_OK;
 }
 
 // page-lock a big input the caller has not pinned (read-only use); returns whether it has to be unlocked afterwards
-static bool pin_input_for_call(const void *h, size_t bytes) {
+static bool pin_input_for_call(const void *h, size_t bytes, unsigned flags = hipHostRegisterDefault) {
     const char *e = getenv("HADES252_HOST_PIN");
     if ((e && e[0] == '0') || bytes < ((size_t)8 << 20) || host_range_pinned(h, bytes)) return false;
-    if (hipHostRegister(const_cast<void *>(h), bytes, hipHostRegisterDefault) == hipSuccess) return true;
+    if (F(F_HOSTREGISTER, hipHostRegister(const_cast<void *>(h), bytes, flags)) == hipSuccess) return true;
     (void)hipGetLastError();
     return false;
 }
@@ -1442,7 +1619,7 @@ struct HostCall {                 // releases what a one-shot host call holds, w
             (void)hipStreamSynchronize(pipe.s_k);
             (void)hipStreamSynchronize(pipe.s_out);
             (void)hipGetLastError();
-            release_pipe(pipe);
+            release_pipe(pipe, code != HADES252_OK);
             have_pipe = false;
         }
         if (registered) (void)hipHostUnregister(const_cast<void *>(registered));
@@ -1461,8 +1638,10 @@ struct HostCall {                 // releases what a one-shot host call holds, w
         }                                              \
     } while (0)
 
-int hades252_merkle_root(const uint64_t *leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
-                         const uint64_t *pad, uint64_t root[4]) {
+// no_pin: the caller (hades252_merkle_root_multi) has already dealt with page-locking for the whole input -- a
+// sub-range attempt here would race with the neighbouring workers over shared boundary pages
+static int merkle_root_host(const uint64_t *leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
+                            const uint64_t *pad, uint64_t root[4], bool no_pin) {
     const int depth = hades252_merkle_depth(n_leaves, arity);
     if (leaves == nullptr || root == nullptr || tag_mont == nullptr || depth < 1 || out_idx < 0 || out_idx >= 5)
         return HADES252_ERR_INVALID_ARG;
@@ -1485,17 +1664,17 @@ int hades252_merkle_root(const uint64_t *leaves, size_t n_leaves, int arity, con
     uint8_t *d_pad = (uint8_t *)pp.aux, *d_root = d_pad + (size_t)depth * 32, *d_l1 = d_pad + head;
     uint8_t *buf_a = d_l1 + n1 * 32, *buf_b = buf_a + ((n1 + arity - 1) / arity) * 32;
     const Fr tag = fr_from_u64(tag_mont);
-    if (pad != nullptr) TRY_CALL(call, hipMemcpyAsync(d_pad, pad, (size_t)depth * 32, hipMemcpyHostToDevice, pp.s_k));
+    if (pad != nullptr) TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d_pad, pad, (size_t)depth * 32, hipMemcpyHostToDevice, pp.s_k)));
     const uint8_t *dp = pad != nullptr ? d_pad : nullptr;
-    if (pin_input_for_call(leaves, n_leaves * 32)) call.registered = leaves;
+    if (!no_pin && pin_input_for_call(leaves, n_leaves * 32)) call.registered = leaves;
     const uint8_t *h = (const uint8_t *)leaves;
     const size_t n_chunks = (n_leaves + chunk - 1) / chunk;
     for (size_t c = 0; c < n_chunks; c++) {                           // level 1, chunk by chunk behind the copies
         const int k = (int)(c % kPipeSlots);
         const size_t off = c * chunk, n = n_leaves - off < chunk ? n_leaves - off : chunk;
         uint8_t *d = (uint8_t *)pp.buf + (size_t)k * pp.slot_cap;
-        if (c >= (size_t)kPipeSlots) TRY_CALL(call, hipEventSynchronize(pp.k_done[k]));   // chunk c - kPipeSlots is hashed
-        TRY_CALL(call, hipMemcpyAsync(d, h + off * 32, n * 32, hipMemcpyHostToDevice, pp.s_in));
+        if (c >= (size_t)kPipeSlots) TRY_CALL(call, F(F_SYNC, hipEventSynchronize(pp.k_done[k])));   // chunk c - kPipeSlots is hashed
+        TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d, h + off * 32, n * 32, hipMemcpyHostToDevice, pp.s_in)));
         TRY_CALL(call, hipEventRecord(pp.in_done[k], pp.s_in));
         TRY_CALL(call, hipStreamWaitEvent(pp.s_k, pp.in_done[k], 0));
         launch_merkle_any(arity, d, n, n1 == 1 ? d_root : d_l1 + (off / arity) * 32, tag, out_idx, dp, pp.s_k);
@@ -1507,9 +1686,16 @@ int hades252_merkle_root(const uint64_t *leaves, size_t n_leaves, int arity, con
                         pp.s_k);
         if (rc != HADES252_OK) return call.finish(rc);
     }
-    TRY_CALL(call, hipMemcpyAsync(root, d_root, 32, hipMemcpyDeviceToHost, pp.s_k));
-    TRY_CALL(call, hipStreamSynchronize(pp.s_k));
+    uint64_t got[4];                                                   // the caller's root is written on success only
+    TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(got, d_root, 32, hipMemcpyDeviceToHost, pp.s_k)));
+    TRY_CALL(call, F(F_SYNC, hipStreamSynchronize(pp.s_k)));
+    memcpy(root, got, 32);
     return call.finish(HADES252_OK);
+}
+
+int hades252_merkle_root(const uint64_t *leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
+                         const uint64_t *pad, uint64_t root[4]) {
+    return merkle_root_host(leaves, n_leaves, arity, tag_mont, out_idx, pad, root, false);
 }
 
 int hades252_sponge_hash(const uint64_t *msgs, size_t n_msgs, size_t msg_len, const uint64_t capacity_mont[4],
@@ -1540,18 +1726,18 @@ int hades252_sponge_hash(const uint64_t *msgs, size_t n_msgs, size_t msg_len, co
         const int k = (int)(c % kPipeSlots);
         const size_t off = c * chunk, n = n_msgs - off < chunk ? n_msgs - off : chunk;
         uint8_t *d = (uint8_t *)pp.buf + (size_t)k * pp.slot_cap, *dd = (uint8_t *)pp.aux + (size_t)k * chunk * 32;
-        if (c >= (size_t)kPipeSlots) TRY_CALL(call, hipEventSynchronize(pp.out_done[k]));
-        if (msg_bytes) TRY_CALL(call, hipMemcpyAsync(d, h + off * msg_bytes, n * msg_bytes, hipMemcpyHostToDevice, pp.s_in));
+        if (c >= (size_t)kPipeSlots) TRY_CALL(call, F(F_SYNC, hipEventSynchronize(pp.out_done[k])));
+        if (msg_bytes) TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d, h + off * msg_bytes, n * msg_bytes, hipMemcpyHostToDevice, pp.s_in)));
         TRY_CALL(call, hipEventRecord(pp.in_done[k], pp.s_in));
         TRY_CALL(call, hipStreamWaitEvent(pp.s_k, pp.in_done[k], 0));
         rc = sponge_launch(d, nullptr, nullptr, n, msg_len, capacity_mont, pad_mode, dd, pp.s_k, n * msg_len, nullptr, nullptr);
         if (rc != HADES252_OK) return call.finish(rc);
         TRY_CALL(call, hipEventRecord(pp.k_done[k], pp.s_k));
         TRY_CALL(call, hipStreamWaitEvent(pp.s_out, pp.k_done[k], 0));
-        TRY_CALL(call, hipMemcpyAsync(out + off * 32, dd, n * 32, hipMemcpyDeviceToHost, pp.s_out));
+        TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(out + off * 32, dd, n * 32, hipMemcpyDeviceToHost, pp.s_out)));
         TRY_CALL(call, hipEventRecord(pp.out_done[k], pp.s_out));
     }
-    TRY_CALL(call, hipStreamSynchronize(pp.s_out));
+    TRY_CALL(call, F(F_SYNC, hipStreamSynchronize(pp.s_out)));
     return call.finish(HADES252_OK);
 }
 // The tree sharded over several devices (every GPU builds complete sub-trees, the sub-roots are hashed
@@ -1574,21 +1760,24 @@ int hades252_merkle_root_multi(const uint64_t *leaves, size_t n_leaves, int arit
     if ((size_t)n_workers > n_sub) n_workers = (int)n_sub;
     if (n_sub == 1) return hades252_merkle_root(leaves, n_leaves, arity, tag_mont, out_idx, nullptr, root);
     const size_t per = n_leaves / n_sub;
-    const bool registered = pin_input_for_call(leaves, n_leaves * 32);    // once for all workers (they share pages)
+    // once for all workers (their sub-ranges share boundary pages) and for every device; refused or disabled: the
+    // workers use pageable copies, none of them tries again on its own sub-range
+    const bool registered = pin_input_for_call(leaves, n_leaves * 32, hipHostRegisterPortable);
     std::vector<uint64_t> sub(n_sub * 4);
     std::vector<int> rcs(n_workers, HADES252_OK), hip_errs(n_workers, 0);
     std::vector<std::thread> threads;
     for (int g = 0; g < n_workers; g++) {
         threads.emplace_back([&, g]() {
-            hipError_t err = hipSetDevice(virt ? g % avail : g);
+            hipError_t err = F(F_WORKER, hipSetDevice(virt ? g % avail : g));
             if (err != hipSuccess) {
                 rcs[g] = HADES252_ERR_HIP;
                 hip_errs[g] = (int)err;
                 return;
             }
+            pin_thread_near_device(virt ? g % avail : g);
             const size_t b = n_sub * (size_t)g / n_workers, e = n_sub * (size_t)(g + 1) / n_workers;
             for (size_t t = b; t < e && rcs[g] == HADES252_OK; t++)
-                rcs[g] = hades252_merkle_root(leaves + t * per * 4, per, arity, tag_mont, out_idx, nullptr, &sub[t * 4]);
+                rcs[g] = merkle_root_host(leaves + t * per * 4, per, arity, tag_mont, out_idx, nullptr, &sub[t * 4], true);
             hip_errs[g] = tl_last_hip_error;
         });
     }
@@ -1628,17 +1817,17 @@ int hades252_sponge_hash_var(const uint64_t *scalars, size_t n_scalars, const ui
     uint8_t *d_pool = (uint8_t *)pp.aux, *d_off = d_pool + pool_b, *d_len = d_off + idx_b, *d_dig = d_len + idx_b;
     uint8_t *d_scr = d_dig + dig_b, *d_bad = d_scr + scr_b;
     if (n_scalars && pin_input_for_call(scalars, n_scalars * 32)) call.registered = scalars;
-    if (n_scalars) TRY_CALL(call, hipMemcpyAsync(d_pool, scalars, n_scalars * 32, hipMemcpyHostToDevice, pp.s_k));
-    TRY_CALL(call, hipMemcpyAsync(d_off, offsets, n_msgs * 8, hipMemcpyHostToDevice, pp.s_k));
-    TRY_CALL(call, hipMemcpyAsync(d_len, lengths, n_msgs * 8, hipMemcpyHostToDevice, pp.s_k));
+    if (n_scalars) TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d_pool, scalars, n_scalars * 32, hipMemcpyHostToDevice, pp.s_k)));
+    TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d_off, offsets, n_msgs * 8, hipMemcpyHostToDevice, pp.s_k)));
+    TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d_len, lengths, n_msgs * 8, hipMemcpyHostToDevice, pp.s_k)));
     TRY_CALL(call, hipMemsetAsync(d_bad, 0, 4, pp.s_k));
     rc = hades252_sponge_hash_var_ex_dev(d_pool, n_scalars, (const uint64_t *)d_off, (const uint64_t *)d_len, n_msgs,
                                          capacity_mont, pad_mode, d_dig, (int *)d_bad, d_scr, scr_b, pp.s_k);
     if (rc != HADES252_OK) return call.finish(rc);
     int bad = 0;
-    TRY_CALL(call, hipMemcpyAsync(digests, d_dig, dig_b, hipMemcpyDeviceToHost, pp.s_k));
-    TRY_CALL(call, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, pp.s_k));
-    TRY_CALL(call, hipStreamSynchronize(pp.s_k));
+    TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(digests, d_dig, dig_b, hipMemcpyDeviceToHost, pp.s_k)));
+    TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, pp.s_k)));
+    TRY_CALL(call, F(F_SYNC, hipStreamSynchronize(pp.s_k)));
     if (n_bad != nullptr) *n_bad = (size_t)bad;
     return call.finish(HADES252_OK);
 }

@@ -288,7 +288,13 @@ struct LanesTables {
     uint32_t p[kNL], pinv[kNL];
 };
 struct LanesLds {               // per wave
-    uint32_t xw[16][8];         // [limb][word]: words 0..4 + three dummy slots (row-private copies of B)
+    // [parity][limb][word]: words 0..4 + three dummy slots (row-private copies of B).  Two buffers: in the helped form a
+    // state wave and the helper meet at ONE barrier per full round, so the buffer of round r may still be being read by
+    // the peer while the other side already publishes for round r + 1 -- full round r uses xw[r & 1] (what
+    // hades_coop.hpp does with its ping-pong buffers); the partial rounds and both hand-overs of word 3 use xw[0], which
+    // the helper last read in round 2 (before the barrier of round 3) and reads again only after the hand-over barrier.
+    // With that no access of one side can overtake the other's by less than a full barrier, whatever the timing.
+    uint32_t xw[2][16][8];
     uint32_t io[8][16];         // [word][limb]: 5 words + dummy rows
 };
 
@@ -350,7 +356,8 @@ __device__ __forceinline__ Fr lanes_perm(const LanesTables *T, LanesLds &L, cons
         stamps[0] = __builtin_amdgcn_s_memtime();
     }
     // Three loops (4 full, 59 partial, 4 full rounds: src/strategies.rs:144-156), each with a straight-line body.
-    auto full_round = [&](bool take_word3) {
+    auto full_round = [&](bool take_word3, int par) {                // par: exchange buffer = round & 1 (helped form)
+        uint32_t (&xw)[16][8] = L.xw[HELPED ? par : 0];
         rec += 64;
         const uint32_t n_a = rec[off_a], n_b = rec[off_b], n_g = rec[off_g];
         unsigned long long ts0 = 0, ts1 = 0;
@@ -359,10 +366,10 @@ __device__ __forceinline__ Fr lanes_perm(const LanesTables *T, LanesLds &L, cons
         A += c_a;
         if constexpr (HELPED) {
             A = lane_sbox(K, A);                                                      // words 4, 0, 1, 2
-            L.xw[k][word_a] = A;
+            xw[k][word_a] = A;
             __syncthreads();                                                          // the helper has stored word 3
-            const uint4 q = *reinterpret_cast<const uint4 *>(&L.xw[k][0]);
-            x[4] = L.xw[k][4];
+            const uint4 q = *reinterpret_cast<const uint4 *>(&xw[k][0]);
+            x[4] = xw[k][4];
             x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
         } else {
             B += c_b;
@@ -370,10 +377,10 @@ __device__ __forceinline__ Fr lanes_perm(const LanesTables *T, LanesLds &L, cons
             lane_sbox_n<2>(K, v);                                                     // two S-boxes, statements interleaved
             A = v[0];
             B = v[1];
-            L.xw[k][word_a] = A;
+            xw[k][word_a] = A;
             lanes_fence();
-            const uint4 q = *reinterpret_cast<const uint4 *>(&L.xw[k][0]);          // .w (word 3) is stale: not used
-            x[4] = L.xw[k][4];
+            const uint4 q = *reinterpret_cast<const uint4 *>(&xw[k][0]);            // .w (word 3) is stale: not used
+            x[4] = xw[k][4];
             x[0] = q.x; x[1] = q.y; x[2] = q.z;
             x[3] = wave_bcast_row<1>(B);
         }
@@ -407,10 +414,10 @@ __device__ __forceinline__ Fr lanes_perm(const LanesTables *T, LanesLds &L, cons
         const uint32_t p1 = lane_mont_mul(K, ab, b1, lane_shifts(b1));            // row 0: x^2;  rows 1..3: w G
         const uint32_t a2 = row0 ? p1 : B, b2 = row0 ? p1 : c_g;
         const uint32_t p2 = lane_mont_mul(K, lane_bcasts(a2), b2, lane_shifts(b2));       // row 0: x^4;  row 1: w_3 G
-        L.xw[k][row0 ? 5 : word_a] = p1;                                              // words 0, 1, 2 (row 0 parks x^2)
-        L.xw[k][slot_b] = p2;                                                         // word 3
+        L.xw[0][k][row0 ? 5 : word_a] = p1;                                           // words 0, 1, 2 (row 0 parks x^2)
+        L.xw[0][k][slot_b] = p2;                                                      // word 3
         lanes_fence();
-        const uint4 q = *reinterpret_cast<const uint4 *>(&L.xw[k][0]);
+        const uint4 q = *reinterpret_cast<const uint4 *>(&L.xw[0][k][0]);
         x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
         const uint32_t p3 = lane_mont_mul(K, ab, p2, lane_shifts(p2));            // row 0: x x^4
         x[4] = wave_bcast_row<0>(p3);
@@ -431,16 +438,16 @@ __device__ __forceinline__ Fr lanes_perm(const LanesTables *T, LanesLds &L, cons
         asm volatile("" : "+v"(A), "+v"(B));
     };
 #pragma unroll 1
-    for (int r = 0; r < 3; r++) full_round(false);
-    full_round(true);                                                // round 3: this wave takes word 3 for the partial rounds
+    for (int r = 0; r < 3; r++) full_round(false, r & 1);
+    full_round(true, 1);                                             // round 3: this wave takes word 3 for the partial rounds
 #pragma unroll 1
     for (int r = 4; r < 63; r++) partial_round();
     if constexpr (HELPED) {                                          // word 3 goes back to the helper
-        L.xw[k][slot_b] = B;
+        L.xw[0][k][slot_b] = B;
         __syncthreads();
     }
 #pragma unroll 1
-    for (int r = 63; r < 67; r++) full_round(false);
+    for (int r = 63; r < 67; r++) full_round(false, r & 1);
     if (stamps != nullptr) stamps[1] = __builtin_amdgcn_s_memtime();
     // ---- out: the words go back to one lane each for the final product and the full reduction
     if constexpr (HELPED) __syncthreads();                           // the helper has stored the final word 3 in io[3]
@@ -481,18 +488,19 @@ __device__ __forceinline__ void lanes_helper(const LanesTables *T, LanesLds (&Ls
     for (int i = 0; i < 8; i++) {
         if (i == 4) {                                                // partial rounds: word 3 is with the main waves
             __syncthreads();
-            H = L.xw[k][3];
+            H = L.xw[0][k][3];
         }
+        uint32_t (&xw)[16][8] = L.xw[i < 4 ? (i & 1) : ((i + 1) & 1)];   // rounds 0..3 and 63..66: buffer = round & 1
         uint32_t c = cb[0];
 #pragma unroll
         for (int j = 1; j < 8; j++) c = i == j ? cb[j] : c;
         H += c;
         H = lane_sbox(K, H);
-        L.xw[k][slot] = H;
+        xw[k][slot] = H;
         __syncthreads();
         uint32_t x[5];
-        const uint4 q = *reinterpret_cast<const uint4 *>(&L.xw[k][0]);
-        x[4] = L.xw[k][4];
+        const uint4 q = *reinterpret_cast<const uint4 *>(&xw[k][0]);
+        x[4] = xw[k][4];
         x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
         H = lane_mds_row(cb_m, x, pk);
         asm volatile("" : "+v"(H));

@@ -62,3 +62,9 @@ __global__ void __launch_bounds__(kBlock) k_digest(const uint64_t *__restrict__ 
     __syncthreads();
     if (threadIdx.x < 4) atomicAdd(&out4[(first_index + threadIdx.x) & 3], part[threadIdx.x]);
 }
+
+// one scalar passed BY VALUE into device memory (hades252_merkle_empty_digests_dev: a captured graph must not keep a
+// pointer into the caller's host memory)
+__global__ void k_store_fr(uint32_t *__restrict__ out, Fr v) {
+    if (threadIdx.x < 8) out[threadIdx.x] = v.l[threadIdx.x];
+}

@@ -206,6 +206,39 @@ class ScalarStrategy(Strategy):
             self.apply_full_round(constants, data)
 
 
+def kernel_for(n_perms: int) -> int:
+    """The selector ``hades252_perm_batch_dev`` runs for a batch of n_perms states (the library's one size rule)."""
+    return _lib.lib().hades252_kernel_for(n_perms)
+
+
+def chain_form_for(n_chains: int) -> int:
+    """The form the chain entry points (sponge, absorb, verify, update) and Merkle levels run for n_chains chains."""
+    return _lib.lib().hades252_chain_form_for(n_chains)
+
+
+def kernel_name(kernel: int = _lib.KERNEL_DEFAULT, n_perms: int = 0) -> str:
+    """Name of the __global__ function a profiler shows for ``hades252_perm_batch_dev_ex(.., n_perms, .., kernel)``."""
+    name = _lib.lib().hades252_kernel_name(kernel, n_perms)
+    if name is None:
+        raise ValueError("unknown kernel selector %r" % (kernel,))
+    return name.decode()
+
+
+def trim() -> None:
+    """``hades252_trim``: give back everything the pool of pipes caches (device memory, streams, staging buffers)."""
+    check(_lib.lib().hades252_trim(), "trim")
+
+
+def pool_bytes() -> int:
+    """``hades252_pool_bytes``: device memory the pool holds right now."""
+    return int(_lib.lib().hades252_pool_bytes())
+
+
+def fault_inject(spec: str | None) -> None:
+    """Test hook ``hades252_fault_inject``: "<site>:<nth>" arms, None disarms."""
+    check(_lib.lib().hades252_fault_inject(None if spec is None else spec.encode()), "fault_inject")
+
+
 class HostBuffer:
     """Page-locked host memory for the host-pointer path (``hades252_host_alloc`` / ``_free``): what a Rust caller
     keeps its long-lived ``Vec<BlsScalar>`` in, so that ``perm`` goes straight to DMA instead of page-locking the

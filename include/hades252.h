@@ -56,18 +56,28 @@ extern "C" {
 #define HADES252_ERR_OUT_OF_CONSTANTS (-6) /* cursor + WIDTH > 960: the reference panics with
                                               "Hades252 out of ARK constants" (src/strategies.rs:40) */
 
-/* kernel selectors for hades252_perm_batch_dev_ex (both produce identical bits) */
+/* kernel selectors for hades252_perm_batch_dev_ex (all produce identical bits) */
 #define HADES252_KERNEL_DEFAULT 0
 #define HADES252_KERNEL_LITERAL 1 /* the reference's round structure, 1972 Montgomery products */
-#define HADES252_KERNEL_FAST 2    /* scale-tracked small-integer MDS formulation, one state per lane */
-#define HADES252_KERNEL_COOP 3    /* same arithmetic, the five words of a state on five waves: less than half the
-                                     latency, ~2/3 of the throughput; DEFAULT picks it for 4096 < n_perms <= 16384 */
-#define HADES252_KERNEL_ROWS 5    /* the same lane arithmetic, one state per 16-lane ROW (four per wave), the throughput
-                                     kernel's schedule: DEFAULT picks it for 1024 < n_perms <= 4096 (~71 us) */
-#define HADES252_KERNEL_LANES 4   /* one state per wave, every field element spread over a 16-lane row (products by the
-                                     row, lane-parallel carries): the lowest latency for ONE permutation -- the
-                                     reference's own call shape (README.md:60-61); DEFAULT picks it for n_perms <= 1024
-                                     (up to 768 with a helper wave per three states: 50 us) */
+#define HADES252_KERNEL_FAST 2    /* scale-tracked small-integer MDS formulation, one state per lane:
+                                     the throughput kernel */
+#define HADES252_KERNEL_COOP 3    /* same arithmetic, the five words of a state on five waves: ~104 us per
+                                     launch up to 16 384 states, ~45 % of the throughput of FAST */
+#define HADES252_KERNEL_LANES 4   /* one state per wave, every field element spread over a 16-lane row: the
+                                     lowest latency for ONE permutation -- the reference's own call shape
+                                     (README.md:60-61): 50 us up to 768 states (helper wave per three states), 54-57 us up
+                                     to 1 024 */
+#define HADES252_KERNEL_ROWS 5    /* the same lane arithmetic, one state per 16-lane ROW, four per wave, the throughput
+                                     kernel's schedule */
+/* The size rule of HADES252_KERNEL_DEFAULT lives in ONE place, the library: hades252_kernel_for(n) is the selector
+ * hades252_perm_batch_dev(.., n_perms = n, ..) runs (never DEFAULT, never LITERAL); hades252_chain_form_for(n) is the form
+ * the chain entry points (sponge, streaming absorb, path verification, tree update) and the Merkle levels run for n
+ * chains / parents (one of LANES, ROWS, COOP, FAST -- the per-state arithmetic of that kernel); hades252_kernel_name gives
+ * the name of the __global__ function a profiler shows for a selector and batch size ("k_perm_fast", "k_perm_lanes", ..;
+ * NULL for an unknown selector). */
+int hades252_kernel_for(size_t n_perms);
+int hades252_chain_form_for(size_t n_chains);
+const char *hades252_kernel_name(int kernel, size_t n_perms);
 
 /* ---- meta --------------------------------------------------------------------------- */
 /* Strategy::rounds() (src/strategies.rs:160-162): TOTAL_FULL_ROUNDS + PARTIAL_ROUNDS = 67 */
@@ -126,6 +136,31 @@ int hades252_dev_download(void *h_dst, const void *d_src, size_t bytes, void *st
 int hades252_stream_create(void **stream);
 int hades252_stream_destroy(void *stream);
 int hades252_stream_sync(void *stream);
+
+/* ---- what the library caches, and how to give it back ---------------------------------------------------------
+ * The host-pointer entry points reuse "pipes" (three streams, events, chunk buffers and a scratch arena in device memory,
+ * a small page-locked staging buffer) so that a call pays no allocation.  The pool is bounded: per device it keeps at most
+ * 16 pipes and at most HADES252_POOL_MAX_BYTES (environment, default 1 GiB) of device memory -- a pipe coming back from
+ * a big one-shot call gives up its arena / chunk buffers first.  hades252_trim() destroys every pooled pipe (pipes in
+ * use by concurrent calls are untouched and return to the pool later); hades252_pool_bytes() is the device memory the
+ * pool holds right now on all devices.  A long-lived process that shares the GPU with another allocator calls trim after
+ * a burst of large calls. */
+int hades252_trim(void);
+size_t hades252_pool_bytes(void);
+
+/* ---- failure contract of the host-pointer entry points, and the hook that tests it -------------------------------
+ * On HADES252_ERR_HIP from hades252_perm_batch* every 160-byte state of the caller's buffer holds EITHER its input OR
+ * its permutation, never anything else (after a call of one chunk -- up to 65 536 states -- the buffer is either
+ * untouched or completely written); which states were completed is unspecified: the call streams chunks in place, so making the whole batch atomic
+ * would cost a second copy of it.  Every stream has drained when the call returns, nothing is leaked, the pipe is
+ * destroyed rather than pooled, and the next call works.  hades252_merkle_root[_multi] write the root only on
+ * success; a failing sponge call may already have delivered the digests of its first chunks.
+ * Test hook: hades252_fault_inject("<site>:<nth>") makes the nth (1-based) HIP call of that class made by the
+ * library from now on fail as if the runtime had refused it; sites: malloc, hostmalloc, hostregister, memcpy,
+ * streamcreate, eventcreate, sync, worker (the device selection of one worker thread of the _multi entry points).
+ * NULL or "" disarms.  The environment variable HADES252_FAIL_AT holds the same spec for processes that cannot call
+ * the hook (read once, at the first library call).  Disarmed cost: one relaxed load per wrapped call. */
+int hades252_fault_inject(const char *spec);
 
 /* ---- the callers of perm, host memory in, host memory out -------------------------------------------------
  * One-shot forms of the Merkle root and the fixed-length sponge for data that lives in host memory (page-locked or not,
@@ -265,8 +300,8 @@ int hades252_merkle_verify_dev(const void *d_leaves, const uint64_t *d_indices, 
  * operation it serves): the caller has overwritten the leaves d_leaves[d_indices[q]], q < n_updates (device u64; sorted
  * lists do each ancestor once, any order is correct, an index >= n_leaves is ignored); their ancestors in d_tree -- built
  * by hades252_merkle_build[_pad]_dev with the same arity, tag, out_idx and pad -- are recomputed bottom-up in place:
- * at most depth * n_updates permutations, one launch per level, one ancestor per wave for up to 1 024 updates (~51 us a
- * level).  A level with no more parents than updates is recomputed whole. */
+ * at most depth * n_updates permutations, one launch per level, the form per level by hades252_chain_form_for (one
+ * ancestor per wave for up to 1 024 updates: ~51 us a level).  A level with no more parents than updates is recomputed whole. */
 int hades252_merkle_update_dev(const void *d_leaves, void *d_tree, size_t n_leaves, int arity, const uint64_t tag_mont[4],
                                int out_idx, const void *d_pad, const uint64_t *d_indices, size_t n_updates, void *stream);
 /* Forest: n_trees independent trees of leaves_per_tree = arity^k leaves each (leaves contiguous, tree after tree); level l
