@@ -47,9 +47,12 @@ __device__ static constexpr int32_t NEGP29[kNL] = HADES_NEG_P29;          // -p,
 __device__ static constexpr int32_t TWOP29[kNL] = HADES_TWO_P29;          // 2p, normalised limbs
 __device__ static constexpr int32_t MDS_SMALL[5][5] = HADES_FAST_MDS_SMALL;
 
+constexpr int kLinRow = 96;   // a linear-map table: 81 entries + pad (see mont_lin)
 struct FastTables {
     int32_t round[67][64];    // per round {A[5][9] (balanced limbs), K[9], pad}
     int32_t final_f[kNL + 7];
+    int32_t lin[67][kLinRow]; // per round: the linear-map table of K_r (partial rounds; zeros in full rounds)
+    int32_t final_lin[kLinRow];   // ... and of FINAL_F
 };
 
 // One limb product accumulated in place; hipcc selects a single v_mad_i64_i32 for this shape as
@@ -172,6 +175,57 @@ __device__ __forceinline__ F29 mont_mul_small(const F29 &a, int32_t c) {
     return r;
 }
 
+// a * F / Rp for a wave-uniform CONSTANT F, as a linear map instead of a product: 97 multiply-adds instead of 153.
+// A product with a constant is linear in the limbs of a:  a F 2^x = sum_k a_k (F 2^(29 k + x) mod p)  (mod p), so the
+// host tabulates E_k = F 2^(29 (k - 7)) mod p (nine constants of nine non-negative 29-bit limbs; e[9 j + k] = limb j
+// of E_k, column-major: column j's nine multipliers are contiguous for the scalar loads) and the kernel computes
+//     W = sum_k a_k E_k          81 multiply-adds over NINE columns (a product has seventeen)
+// followed by only TWO digit steps of the signed-digit reduction of mont_fips (W - (m_0 + 2^29 m_1) p) / 2^58 -- 16
+// multiply-adds instead of 72 -- because W is already below 2^33 p: the constants were reduced on the host.
+// The result is congruent to W / 2^58 = a F / 2^261, exactly what mont_fips(a, F) returns, and lies in
+// (W / 2^58 - p (1 + 2^-29), W / 2^58].
+// Input: normalised (limbs 0..7 in [0, 2^29), |top limb| < 2^25: the output of mont_fips / small_mds / to_f29).
+// Output: normalised, value in (-p - 2^227, 2^230).  Column bound: 9 * 2^58 + 2 * 2^58 + carry < 2^62.
+// hades252_amd/_derive.py::lin_table builds the table; tests/test_fast_model.py::mont_lin replays this limb for limb.
+__device__ __forceinline__ F29 mont_lin(const F29 &a, const int32_t *e) {
+    int32_t m0 = 0, m1 = 0;
+    F29 r;
+    int64_t acc = 0;
+    // The 81 multipliers arrive by scalar loads, one column (nine contiguous dwords) ahead of the column being summed:
+    // source order + a scheduling barrier per column pin that, so at most two columns of SGPRs are live (left to itself
+    // the scheduler hoists what fits and then fetches the rest dword by dword, each behind its own wait).
+    int32_t cur[kNL], nxt[kNL];
+#pragma unroll
+    for (int k = 0; k < kNL; k++) cur[k] = e[k];
+#pragma unroll
+    for (int j = 0; j < kNL; j++) {
+        if (j + 1 < kNL) {
+#pragma unroll
+            for (int k = 0; k < kNL; k++) nxt[k] = e[kNL * (j + 1) + k];
+        }
+#pragma unroll
+        for (int k = 0; k < kNL; k++) mac(acc, a.l[k], cur[k]);
+        if (j >= 1) mac(acc, m0, NEGP29[j]);
+        if (j >= 2) mac(acc, m1, NEGP29[j - 1]);
+        const int32_t low = (int32_t)((uint32_t)acc & kMask29);
+        if (j == 0)
+            m0 = low;
+        else if (j == 1)
+            m1 = low;
+        else
+            r.l[j - 2] = low;
+        acc >>= kLB;                          // exact for j < 2 (p == 1 mod 2^29), floor afterwards
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < kNL; k++) cur[k] = nxt[k];
+    }
+    mac(acc, m1, NEGP29[kNL - 1]);            // column 9: what is left of m_1 p
+    r.l[kNL - 2] = (int32_t)((uint32_t)acc & kMask29);
+    acc >>= kLB;
+    r.l[kNL - 1] = (int32_t)acc;
+    return r;
+}
+
 __device__ __forceinline__ F29 mont_mul(const F29 &a, const F29 &b) { return mont_fips<false, false>(a, b.l); }
 __device__ __forceinline__ F29 mont_sqr(const F29 &a) { return mont_fips<true, false>(a, a.l); }
 // product with a wave-uniform constant (limbs in SGPRs)
@@ -229,13 +283,9 @@ __device__ __forceinline__ void small_mds(F29 (&st)[5]) {
 // One round.  The reference adds round keys to all five words in both round kinds
 // (src/strategies.rs:86, :111); full rounds S-box every word, partial rounds the last word only,
 // which then takes the rescale product.  `full` is wave-uniform, so the branches are scalar.
-__device__ __forceinline__ void fast_round(const int32_t *rec, bool full, F29 (&st)[5]) {
+__device__ __forceinline__ void fast_round(const int32_t *rec, const int32_t *lin, bool full, F29 (&st)[5]) {
     // partial rounds: the constants of words 0..3 were pushed through the linear layers on the
     // host (hades252_amd/_derive.py), only word 4 receives one
-    // fetch the rescale factor now (scalar loads), ~1500 instructions before it is needed
-    int32_t kr[kNL];
-#pragma unroll
-    for (int k = 0; k < kNL; k++) kr[k] = rec[5 * kNL + k];
     if (full) {
 #pragma unroll
         for (int w = 0; w < 4; w++) add_lazy(st[w], rec + w * kNL);
@@ -248,7 +298,7 @@ __device__ __forceinline__ void fast_round(const int32_t *rec, bool full, F29 (&
         st[3] = sbox29(st[3]);
     }
     st[4] = sbox29(st[4]);
-    if (!full) st[4] = mont_mul_const(st[4], kr);
+    if (!full) st[4] = mont_lin(st[4], lin);            // back to the common scale: x K_r / Rp as a linear map
     small_mds(st);
 #pragma unroll
     for (int w = 0; w < 5; w++)
@@ -256,7 +306,7 @@ __device__ __forceinline__ void fast_round(const int32_t *rec, bool full, F29 (&
         for (int k = 0; k < kNL; k++) limb_fence(st[w].l[k]);
 }
 
-// x = mont_mul_const(state word, FINAL_F): normalised, value in (-p - 2^250, 2^250]
+// x = mont_lin(state word, FINAL_F) or mont_mul_const(., .): normalised, value in (-p - 2^250, 2^250]
 // -> the fully reduced BlsScalar of x mod p
 __device__ __forceinline__ Fr finalize(const F29 &x) {
     // x + 2p lies in (p - 2^250, 2p + 2^250), below 2^256: carry-normalise (all limbs end
@@ -282,16 +332,16 @@ __device__ __forceinline__ void fast_perm(const FastTables *T, const Fr (&in)[5]
     // one loop, one body: every piece of round code exists once in the instruction stream, so the
     // whole kernel stays inside the instruction cache
 #pragma unroll 1
-    for (int r = 0; r < 67; r++) fast_round(T->round[r], r < 4 || r >= 63, st);
+    for (int r = 0; r < 67; r++) fast_round(T->round[r], T->lin[r], r < 4 || r >= 63, st);
     if constexpr (NOUT == 5) {
 #pragma unroll
-        for (int w = 0; w < 5; w++) out[w] = finalize(mont_mul_const(st[w], T->final_f));
+        for (int w = 0; w < 5; w++) out[w] = finalize(mont_lin(st[w], T->final_lin));
     } else {
         F29 sel = st[0];
 #pragma unroll
         for (int w = 1; w < 5; w++)
             if (out_first == w) sel = st[w];
-        out[0] = finalize(mont_mul_const(sel, T->final_f));
+        out[0] = finalize(mont_lin(sel, T->final_lin));
     }
 }
 

@@ -14,7 +14,7 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 // 67 round records {A[5][9], K[9]} + the final un-scaling factor, 17 KiB.  Every access is wave-uniform: hipcc emits
 // s_load_dwordx8/x16 through the scalar cache and the limbs arrive in SGPRs, consumed directly as v_mad_i64_i32
 // operands (no VGPR, no LDS bandwidth, no VALU slot: DESIGN.md section 2; A/B against an LDS copy: profiles/r3/).
-__device__ const FastTables d_fast = {HADES_FAST_ROUND_INIT, HADES_FAST_FINAL_F};
+__device__ const FastTables d_fast = {HADES_FAST_ROUND_INIT, HADES_FAST_FINAL_F, HADES_FAST_LIN_INIT, HADES_FAST_FINAL_LIN};
 
 template <int NW>
 __device__ __forceinline__ uint8_t *wave_slab(uint8_t *lds) {

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__
     }
 #pragma unroll 1
     for (int r = 0; r < 67; r++) {
-        fast_round(d_fast.round[r], r < 4 || r >= 63, st);
+        fast_round(d_fast.round[r], d_fast.lin[r], r < 4 || r >= 63, st);
         const int32_t *u = d_trace_u[r];
 #pragma unroll
         for (int w = 0; w < 5; w++) {

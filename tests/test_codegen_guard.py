@@ -4,8 +4,10 @@ The shipped kernel's speed rests on two compiler-facing tricks in hades_fast.hpp
 them every limb product is ONE `v_mad_i64_i32`; without them LLVM widens limbs to 64 bits (two multiply-adds
 and two moves per product) or re-associates column sums (an extra 64-bit add per column).  A ROCm bump could
 silently undo either.  This test compiles the device code to assembly for gfx950 and asserts, per kernel:
-  k_perm_fast      v_mad_i64_i32 within +-2 % of 2898, no v_mad_u64_u32 beyond the staging/finalize few,
-                   0 scratch, <= 96 VGPRs (=> 5 waves/SIMD by registers)
+  k_perm_fast      v_mad_i64_i32 within +-2 % of 2562 (round 4: constant products as linear maps, 97 multiply-adds
+                   instead of 153), no v_mad_u64_u32 beyond the staging/finalize few, 0 scratch, <= 112 VGPRs (=> 4
+                   waves/SIMD by registers; the LDS slab admits 3), the linear map's multipliers fetched a column at a
+                   time (no dword-by-dword scalar loads)
   every hot kernel 0 scratch (sponge, Merkle, trace, cooperative, per-lane level) -- round 1's sponge spilled
 """
 import os
@@ -58,13 +60,17 @@ def test_perm_fast_instruction_mix(device_asm):
     body = bodies[name]
     mads = len(re.findall(r"\bv_mad_i64_i32\b", body))
     umads = len(re.findall(r"\bv_mad_u64_u32\b", body))
-    assert abs(mads - 2898) <= 0.02 * 2898, "one multiply-add per limb product no longer holds: %d v_mad_i64_i32" % mads
+    assert abs(mads - 2562) <= 0.02 * 2562, "one multiply-add per limb product no longer holds: %d v_mad_i64_i32" % mads
     assert umads <= 300, "%d v_mad_u64_u32: limbs are being widened to 64 bits?" % umads
     total = len([l for l in body.splitlines() if re.match(r"\s+[vs]_", l)])
     assert total < 5600, "kernel grew to %d instructions (I-cache: 64 KB ~ 8 k instructions of 8 B)" % total
     r = res[name]
     assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0
-    assert r["VGPRs"] <= 96, r
+    assert r["VGPRs"] <= 112, r
+    # mont_lin's 81 multipliers per partial round arrive as one s_load_dwordx8 + one s_load_dword per column, a column
+    # ahead; left to itself the scheduler fetched them dword by dword, each behind its own wait
+    singles = len(re.findall(r"\bs_load_dword\b", body))
+    assert singles <= 16, "%d single-dword scalar loads: the column staging of mont_lin got lost" % singles
 
 
 @pytest.mark.parametrize("needle", ["k_perm_fast", "k_sponge", "k_merkle_level_fast", "k_merkle_coop", "k_perm_coop",

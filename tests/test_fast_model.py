@@ -72,6 +72,44 @@ def mont_fips(a, b, sqr=False):
     return r
 
 
+def mont_lin(a, factor):
+    """mont_lin of hades_fast.hpp: a * factor / Rp for a CONSTANT factor as a linear map over the limbs of a (table
+    D.lin_table) + two signed-digit steps.  Same congruence class as mont_fips(a, factor)."""
+    assert all(0 <= x < (1 << LB) for x in a[:-1]) and abs(a[-1]) < (1 << 25), "input must be normalised"
+    e = D.lin_table(factor)
+    assert len(e) == 81 and all(0 <= x < (1 << LB) for x in e)
+    m = [0, 0]
+    r = [0] * NL
+    acc = 0
+    for j in range(NL):
+        for k in range(NL):
+            acc += a[k] * e[NL * j + k]
+            check_acc(acc)
+        if j >= 1:
+            acc -= m[0] * P29[j]
+        if j >= 2:
+            acc -= m[1] * P29[j - 1]
+        assert abs(acc) < (1 << 62)
+        low = acc & MASK
+        if j < 2:
+            m[j] = low
+            assert (acc - low) % (1 << LB) == 0
+        else:
+            r[j - 2] = low
+        acc >>= LB
+    acc -= m[1] * P29[NL - 1]
+    r[NL - 2] = acc & MASK
+    acc >>= LB
+    assert -(1 << 25) < acc < (1 << 25)
+    r[NL - 1] = acc
+    v, steps = val(r), D.LIN_STEPS
+    w = sum(a[k] * (factor * pow(2, LB * (k + steps - NL), P) % P) for k in range(NL))
+    assert w - ((1 << (LB * steps)) - 1) * P <= v << (LB * steps) <= w, "result outside (W/2^58 - p, W/2^58]"
+    assert (v - val(a) * factor * pow(1 << (LB * NL), -1, P)) % P == 0, "not congruent to a * factor / Rp"
+    assert -P - (1 << 227) < v < (1 << 230)
+    return r
+
+
 def small_mds(st):
     acc = [0] * 5
     m = [0] * 5
@@ -135,17 +173,16 @@ def fast_perm_model(mont_vals, trace=None):
         if full:
             st = [sbox(x) for x in st]
         else:
-            st[4] = mont_fips(sbox(st[4]), D.to_limbs29(k))
+            st[4] = mont_lin(sbox(st[4]), k)
         st = small_mds(st)
         for x in st:
             assert normalised(x)
         if trace is not None:
             trace.append([(finalize_model(x, sch["trace_u"][r]) + sch["trace_d"][r][w] * S.R) % P
                           for w, x in enumerate(st)])
-    f = D.to_limbs29(sch["final_f"])
     out = []
     for x in st:
-        v = val(mont_fips(x, f))
+        v = val(mont_lin(x, sch["final_f"]))
         assert -2 * P < v < P
         v += 2 * P                       # finalize(): + 2p, then two conditional subtractions
         assert 0 < v < 3 * P and v < (1 << 256)
