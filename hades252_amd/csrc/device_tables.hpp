@@ -23,7 +23,7 @@ __device__ const LanesTables d_lanes = {HADES_LANES_ROUND_INIT, HADES_COOP_FINAL
 __device__ const LanesTables d_rows = {HADES_ROWS_ROUND_INIT, HADES_FAST_FINAL_F, HADES_FAST_MDS_SMALL, HADES_P29,
                                         HADES_P29, HADES_NEG_PINV29};
 // trace kernel: U_r with mont(X_after_round_r, U_r) = x * 2^256
-__device__ const int32_t d_trace_u[67][16] = HADES_FAST_TRACE_U_INIT;
+__device__ const int32_t d_trace_lin[67][kLinRow] = HADES_FAST_TRACE_LIN_INIT;        // as linear maps (mont_lin)
 // ... + D_r: the partial-round constants of words 0..3 that the shipped schedule defers (hades_fast.hpp item 5)
 __device__ const uint32_t d_trace_d[67][5][8] = HADES_FAST_TRACE_D_INIT;
 // witness kernel: un-scaling factors {u_in,u2,u4,u5,w1,u_post} and additive corrections {d1[5], d2[5]} per round
@@ -35,12 +35,15 @@ __device__ const WitnessTables d_wit = {HADES_WITNESS_U_INIT, HADES_WITNESS_D_IN
 // generic radix-2^29 field ops (hades252_fr_op_dev)
 __device__ const int32_t d_rp_mod_p[16] = HADES_RP_MOD_P29;
 // per-operation kernels on the same path (hades252_amd/_derive.py)
-__device__ const int32_t d_op_k[16] = HADES_OP_K29;
-__device__ const int32_t d_op_w[16] = HADES_OP_W29;
-__device__ const int32_t d_op_w_full[16] = HADES_OP_W_FULL29;
+__device__ const int32_t d_op_k_lin[kLinRow] = HADES_OP_K_LIN;                        // linear maps (mont_lin)
+__device__ const int32_t d_op_w_lin[kLinRow] = HADES_OP_W_LIN;
+__device__ const int32_t d_op_w_full_lin[kLinRow] = HADES_OP_W_FULL_LIN;
 // wire format (from_bytes / to_bytes) on the same path
-__device__ const int32_t d_rp_times_r[16] = HADES_RP_TIMES_R29;
-__device__ const int32_t d_rp_over_r[16] = HADES_RP_OVER_R29;
+// a -> a * 2^256 as a linear map (mont_lin).  __constant__ and NOT const on purpose: a const table is folded into 81 literal
+// s_mov_b32 per scalar (one per multiply-add, on the CU's single scalar unit, plus hazard s_nops around the multiply-add's
+// SGPR carry-out); a plain __device__ global is read with VECTOR loads; in the constant address space, its value unknown
+// to the compiler, it arrives by one s_load_dwordx8 + s_load_dword per column like the round tables do.
+__constant__ int32_t d_wire_from_lin[kLinRow] = HADES_WIRE_FROM_LIN;
 __device__ const int32_t d_rp2_over_r[16] = HADES_RP2_OVER_R29;
 
 // ---- access to 32-byte words, small helpers shared by the kernel headers ------------------------------------

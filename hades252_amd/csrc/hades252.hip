@@ -978,7 +978,7 @@ int hades252_from_bytes_dev(const void *d_bytes, void *d_limbs, size_t n_scalars
     if (d_bytes == nullptr || d_limbs == nullptr || n_scalars > kMaxLaunchRecords || misaligned(d_bytes) ||
         misaligned(d_limbs))
         return HADES252_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_wire<1>, dim3(blocks_for((n_scalars + kWirePerThread - 1) / kWirePerThread)), dim3(kBlock), 0,
+    hipLaunchKernelGGL(k_wire<1>, dim3(blocks_for((n_scalars + kWireU<1> - 1) / kWireU<1>)), dim3(kBlock), 0,
                        (hipStream_t)stream, (const uint8_t *)d_bytes, (uint8_t *)d_limbs, n_scalars, d_bad_count);
     HIP_TRY(hipGetLastError());
     return HADES252_OK;
@@ -989,7 +989,7 @@ int hades252_to_bytes_dev(const void *d_limbs, void *d_bytes, size_t n_scalars, 
     if (d_bytes == nullptr || d_limbs == nullptr || n_scalars > kMaxLaunchRecords || misaligned(d_bytes) ||
         misaligned(d_limbs))
         return HADES252_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_wire<0>, dim3(blocks_for((n_scalars + kWirePerThread - 1) / kWirePerThread)), dim3(kBlock), 0,
+    hipLaunchKernelGGL(k_wire<0>, dim3(blocks_for((n_scalars + kWireU<0> - 1) / kWireU<0>)), dim3(kBlock), 0,
                        (hipStream_t)stream, (const uint8_t *)d_limbs, (uint8_t *)d_bytes, n_scalars, (int *)nullptr);
     HIP_TRY(hipGetLastError());
     return HADES252_OK;

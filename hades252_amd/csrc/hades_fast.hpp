@@ -45,6 +45,7 @@ struct F29 {
 
 __device__ static constexpr int32_t NEGP29[kNL] = HADES_NEG_P29;          // -p, limb by limb
 __device__ static constexpr int32_t TWOP29[kNL] = HADES_TWO_P29;          // 2p, normalised limbs
+__device__ static constexpr int32_t P29[kNL] = HADES_P29;                 // p, normalised limbs
 __device__ static constexpr int32_t MDS_SMALL[5][5] = HADES_FAST_MDS_SMALL;
 
 constexpr int kLinRow = 96;   // a linear-map table: 81 entries + pad (see mont_lin)
@@ -170,6 +171,11 @@ __device__ __forceinline__ F29 mont_mul_small(const F29 &a, int32_t c) {
         else
             r.l[k - kNL] = low;
         acc >>= kLB;
+        // Ties the volatile statements to the data flow once per column: in a straight-line caller (k_wire) nothing else
+        // does, and hipcc then runs the whole arithmetic first and the empty `pin` statements afterwards, which keeps
+        // EVERY partial sum alive until then (197 VGPRs, or 536 bytes of scratch under launch bounds).  A read-write
+        // statement cannot leave the chain, and the pins cannot cross it.
+        asm volatile("" : "+v"(acc));
     }
     r.l[kNL - 1] = (int32_t)acc;
     return r;
@@ -321,6 +327,21 @@ __device__ __forceinline__ Fr finalize(const F29 &x) {
     }
     y.l[kNL - 1] = x.l[kNL - 1] + TWOP29[kNL - 1] + carry;
     return fr_cond_sub_p(fr_cond_sub_p(from_f29(y)));
+}
+
+// The same for x known to lie in (-p, p) -- mont_mul_small of a reduced input: (-p, 0]; mont_lin of non-negative limbs:
+// (-p, 2^-25 p) -- where x + p is in (0, 2p): ONE conditional subtraction.
+__device__ __forceinline__ Fr finalize1(const F29 &x) {
+    F29 y;
+    int32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < kNL - 1; k++) {
+        int32_t v = x.l[k] + P29[k] + carry;
+        y.l[k] = (int32_t)((uint32_t)v & kMask29);
+        carry = v >> kLB;
+    }
+    y.l[kNL - 1] = x.l[kNL - 1] + P29[kNL - 1] + carry;
+    return fr_cond_sub_p(from_f29(y));
 }
 
 // in: 5 BlsScalars (Montgomery 2^256 form, fully reduced); out: same format, fully reduced.

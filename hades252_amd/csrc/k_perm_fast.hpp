@@ -14,7 +14,9 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 // 67 round records {A[5][9], K[9]} + the final un-scaling factor, 17 KiB.  Every access is wave-uniform: hipcc emits
 // s_load_dwordx8/x16 through the scalar cache and the limbs arrive in SGPRs, consumed directly as v_mad_i64_i32
 // operands (no VGPR, no LDS bandwidth, no VALU slot: DESIGN.md section 2; A/B against an LDS copy: profiles/r3/).
-__device__ const FastTables d_fast = {HADES_FAST_ROUND_INIT, HADES_FAST_FINAL_F, HADES_FAST_LIN_INIT, HADES_FAST_FINAL_LIN};
+// (__constant__ and not const: the compiler must not fold the final linear map's 81 multipliers into literal s_mov_b32,
+// one per multiply-add -- device_tables.hpp, d_wire_from_lin)
+__constant__ FastTables d_fast = {HADES_FAST_ROUND_INIT, HADES_FAST_FINAL_F, HADES_FAST_LIN_INIT, HADES_FAST_FINAL_LIN};
 
 template <int NW>
 __device__ __forceinline__ uint8_t *wave_slab(uint8_t *lds) {

@@ -59,10 +59,10 @@ __global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__
 #pragma unroll 1
     for (int r = 0; r < 67; r++) {
         fast_round(d_fast.round[r], d_fast.lin[r], r < 4 || r >= 63, st);
-        const int32_t *u = d_trace_u[r];
+        const int32_t *u = d_trace_lin[r];
 #pragma unroll
         for (int w = 0; w < 5; w++) {
-            Fr v = finalize(mont_mul_const(st[w], u));
+            Fr v = finalize(mont_lin(st[w], u));
             if (r >= 4 && r < 63) v = fr_add(v, load_const(d_trace_d[r], w));
             slab_put<5>(slab, w, v);
         }
@@ -248,12 +248,12 @@ __global__ void __launch_bounds__(kBlock, 3) k_states_fast(uint8_t *states, size
             for (int k = 0; k < kNL; k++) limb_fence(st[4].l[k]);
         }
     }
-    if constexpr (OP == OP_PARTIAL) st[4] = mont_mul_const(sbox29(st[4]), d_op_k);
+    if constexpr (OP == OP_PARTIAL) st[4] = mont_lin(sbox29(st[4]), d_op_k_lin);
     small_mds(st);
-    const int32_t *u = OP == OP_FULL ? d_op_w_full : d_op_w;
+    const int32_t *u = OP == OP_FULL ? d_op_w_full_lin : d_op_w_lin;
     Fr out[5];
 #pragma unroll
-    for (int w = 0; w < 5; w++) out[w] = finalize(mont_mul_const(st[w], u));
+    for (int w = 0; w < 5; w++) out[w] = finalize(mont_lin(st[w], u));
     wave_store_records<5>(states, rec0, n, slab, out);
 }
 
@@ -263,39 +263,59 @@ __global__ void __launch_bounds__(kBlock) k_sbox(uint8_t *scalars, size_t n) {
     size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
     Fr st[1];
     wave_load_records<1>(scalars, rec0, n, slab, st);
-    st[0] = finalize(mont_mul_const(sbox29(to_f29(st[0])), d_op_k));
+    st[0] = finalize(mont_lin(sbox29(to_f29(st[0])), d_op_k_lin));
     wave_store_records<1>(scalars, rec0, n, slab, st);
 }
 
 // canonical bytes <-> Montgomery limbs (BlsScalar::from_bytes / to_bytes): 64 B of HBM traffic and ONE constant
-// product per scalar.  The product runs on the radix-2^29 path (mont_mul_const: 153 multiply-adds; the saturated
-// 8x32 product these kernels used in round 1 is ~620 instructions and made them VALU-bound at 3.4-4.5 TB/s).
-// No LDS: every lane reads and writes its own 32 bytes with two 16-byte accesses -- a wave's two instructions
-// together cover 2 KiB contiguous, the second hits the lines the first fetched -- and takes kWirePerThread scalars
-// in a grid-stride loop to keep more bytes in flight.  `out` may be `in` (lane-private in-place update).
-constexpr int kWirePerThread = 4;
+// multiplication per scalar, on the radix-2^29 path:
+//   to_bytes    x / 2^256 = mont_mul_small(x, Rp / 2^256 = 32): the factor is ONE limb, 81 multiply-adds; the result lies
+//               in (-p, 0] for a reduced input, so + p and ONE conditional subtraction finish it (finalize1)
+//   from_bytes  a * 2^256 as a LINEAR MAP over the limbs of a (mont_lin: 97 multiply-adds instead of the 153 of a
+//               Montgomery product; result in (-p, 2^-25 p): finalize1 again); inputs >= p are rejected
+// Memory shape (tools/wire_proto.hip, tools/copy_proto.hip; profiles/r4/wire_proto.txt): no LDS, every lane reads and
+// writes its own 32 bytes with two 16-byte accesses (a wave's two instructions together cover 2 KiB contiguous); ONE
+// trip per thread and no loop -- a plain copy on this part runs 6.19 TB/s with one trip per thread, 5.9 with four,
+// 5.5 with a persistent grid: short-lived waves pace HBM best; kWireU scalars per thread, all loads issued before
+// the first conversion (from_bytes: 2, its longer arithmetic wants more bytes in flight per wave; to_bytes: 1).
+// Non-temporal accesses were slower in every shape.  `out` may be `in` (lane-private in-place update).
 constexpr int32_t kRpOverR = 1 << (kLB * kNL - 256);        // 2^261 / 2^256
+template <int MODE>
+constexpr int kWireU = MODE == 1 ? 2 : 1;
+// Launch bounds: 8 (to_bytes) / 6 (from_bytes) waves per SIMD -- without them hipcc schedules the straight-line body for
+// instruction-level parallelism, takes 197 VGPRs and leaves two waves per SIMD (measured: 4.0 TB/s instead of 5.9).
 template <int MODE>   // 0 = to_bytes (x / 2^256), 1 = from_bytes (a * 2^256, inputs >= p rejected)
-__global__ void __launch_bounds__(kBlock) k_wire(const uint8_t *in, uint8_t *out, size_t n, int *bad_count) {
+__global__ void __launch_bounds__(kBlock, MODE == 1 ? 6 : 8) k_wire(const uint8_t *in, uint8_t *out, size_t n, int *bad_count) {
+    constexpr int U = kWireU<MODE>;
     const size_t stride = (size_t)gridDim.x * kBlock;
-    const int32_t *factor = MODE == 1 ? d_rp_times_r : d_rp_over_r;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(in + i * 32);
-        uint4 lo = p[0], hi = p[1];
-        Fr a;
-        a.l[0] = lo.x; a.l[1] = lo.y; a.l[2] = lo.z; a.l[3] = lo.w;
-        a.l[4] = hi.x; a.l[5] = hi.y; a.l[6] = hi.z; a.l[7] = hi.w;
-        // to_bytes: the factor Rp / 2^256 = 32 is a single limb: 81 multiply-adds instead of 153 (5.0 -> 5.3 TB/s at 2^26
-        // scalars; issuing the next scalar's loads before this one's arithmetic changed nothing: profiles/r3/wire_bw.txt)
-        Fr m = finalize(MODE == 1 ? mont_mul_const(to_f29(a), factor) : mont_mul_small(to_f29(a), kRpOverR));
-        if (MODE == 1 && !fr_is_canonical(a)) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    uint4 lo[U], hi[U];
 #pragma unroll
-            for (int k = 0; k < 8; k++) m.l[k] = 0;
-            if (bad_count != nullptr) atomicAdd(bad_count, 1);
+    for (int u = 0; u < U; u++) {
+        const size_t idx = i + (size_t)u * stride;
+        if (idx < n) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(in + idx * 32);
+            lo[u] = p[0];
+            hi[u] = p[1];
         }
-        uint4 *q = reinterpret_cast<uint4 *>(out + i * 32);
-        q[0] = make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]);
-        q[1] = make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const size_t idx = i + (size_t)u * stride;
+        if (idx < n) {
+            Fr a;
+            a.l[0] = lo[u].x; a.l[1] = lo[u].y; a.l[2] = lo[u].z; a.l[3] = lo[u].w;
+            a.l[4] = hi[u].x; a.l[5] = hi[u].y; a.l[6] = hi[u].z; a.l[7] = hi[u].w;
+            Fr m = finalize1(MODE == 1 ? mont_lin(to_f29(a), d_wire_from_lin) : mont_mul_small(to_f29(a), kRpOverR));
+            if (MODE == 1 && !fr_is_canonical(a)) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) m.l[k] = 0;
+                if (bad_count != nullptr) atomicAdd(bad_count, 1);
+            }
+            uint4 *q = reinterpret_cast<uint4 *>(out + idx * 32);
+            q[0] = make_uint4(m.l[0], m.l[1], m.l[2], m.l[3]);
+            q[1] = make_uint4(m.l[4], m.l[5], m.l[6], m.l[7]);
+        }
     }
 }
 

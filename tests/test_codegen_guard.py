@@ -83,6 +83,15 @@ def test_hot_kernels_have_no_scratch(device_asm, needle):
         assert res[name]["VGPRs Spill"] == 0, (name, res[name])      # (SGPR spills go to VGPR lanes, not memory)
 
 
+def test_wire_kernels_keep_their_occupancy(device_asm):
+    """k_wire is straight-line code: left alone hipcc schedules it for ILP with ~200 VGPRs (2 waves/SIMD, 4.0 TB/s instead
+    of 5.9).  The launch bounds hold it at >= 8 (to_bytes) / >= 6 (from_bytes) waves per SIMD."""
+    _, res = device_asm
+    for name in find(res, "k_wire"):
+        want = 6 if "ILi1E" in name else 8
+        assert res[name]["Occupancy"] >= want, (name, res[name])
+
+
 def test_perm_lanes_instruction_mix(device_asm):
     """The lane-split kernel's latency IS its instruction count (one wave issues one instruction per ~4.4 cycles): a
     product is 28 multiply-adds (9 + 9 + 9 + the column-16 one) and ~45 DPP moves; a partial round runs 3 products, a

@@ -197,6 +197,43 @@ def fast_perm_model(mont_vals, trace=None):
 EDGE = [0, 1, P - 1, S.R, P - S.R, (1 << 255) % P, (1 << 254) - 1]
 
 
+def finalize1_model(v):
+    """finalize1 of hades_fast.hpp: v in (-p, p) -> + p, ONE conditional subtraction."""
+    assert -P < v < P, "finalize1 needs its input in (-p, p)"
+    v += P
+    return v - P if v >= P else v
+
+
+def test_wire_format_models():
+    """k_wire (kernels_perm.hpp): from_bytes = finalize1(mont_lin(a, Rp * R)) -- a linear map over non-negative limbs, so
+    W >= 0 and the two digit steps leave the result in (-p, 2^-25 p) -- and to_bytes = finalize1(mont_mul_small(x, 32)),
+    whose result lies in (-p, 0] for a reduced x.  One conditional subtraction each; checked on edge and random values,
+    and on the largest encodable non-canonical input (rejected by the kernel, but its arithmetic must stay in range)."""
+    rng = random.Random(41)
+    vals = EDGE + [P - 2, (1 << 255) - 19 if (1 << 255) - 19 < P else 5] + [rng.randrange(P) for _ in range(300)]
+    f_from = D.RP * D.R % P
+    for a in vals:
+        w = val(mont_lin(D.to_limbs29(a), f_from))
+        assert -P < w < (P >> 24)
+        assert finalize1_model(w) == a * D.R % P                       # from_bytes: canonical -> Montgomery limbs
+        x = a * D.R % P
+        t = val(mont_fips(D.to_limbs29(x), D.to_limbs29(1 << (LB * NL - 256))))
+        assert -P < t <= 0
+        assert finalize1_model(t) == a                                 # to_bytes: Montgomery limbs -> canonical
+    big = (1 << 256) - 1                                               # not canonical: zeroed by the kernel afterwards
+    assert -P < val(mont_lin(D.to_limbs29(big), f_from)) < P
+
+
+def test_mont_lin_bounds_adversarial():
+    """mont_lin on the largest normalised operands (every limb 2^29 - 1, top limb +-(2^25 - 1)): the model asserts the
+    64-bit column bound, the digit-step exactness and the result range; reachable inputs are smaller."""
+    for top in ((1 << 25) - 1, -((1 << 25) - 1), 0):
+        a = [MASK] * (NL - 1) + [top]
+        for factor in (P - 1, D.RP * D.R % P, D.fast_schedule()["final_f"], D.fast_schedule()["part"][30][1], 1):
+            r = mont_lin(a, factor)
+            assert all(0 <= x < (1 << LB) for x in r[:-1])
+
+
 def test_model_matches_spec_oracle():
     rng = random.Random(29)
     cases = [[1] * 5, [0] * 5, [P - 1] * 5, [17] * 5]
