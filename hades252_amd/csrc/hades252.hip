@@ -10,6 +10,7 @@
 #include <sched.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -447,6 +448,7 @@ struct HostPipe {
     void *pinned_dev = nullptr;   // ... and its device-side address
     void *aux = nullptr;          // grow-only device arena of the one-shot Merkle / sponge calls (levels, digests, tables)
     size_t aux_cap = 0;
+    void *stage = nullptr;        // page-locked staging of the pageable-caller path (perm_batch_host_staged), 120 MiB
 };
 // Calls of at most this many states skip both DMA copies: the states are copied (by the CPU) into a
 // page-locked buffer that the kernel reads and writes over PCIe itself -- one launch + one synchronisation.
@@ -456,6 +458,7 @@ static std::vector<HostPipe> g_pool;
 
 static void destroy_pipe(HostPipe &p) {
     if (p.pinned) (void)hipHostFree(p.pinned);
+    if (p.stage) (void)hipHostFree(p.stage);
     if (p.buf) (void)hipFree(p.buf);
     if (p.aux) (void)hipFree(p.aux);
     for (int i = 0; i < kPipeSlots; i++) {
@@ -618,6 +621,145 @@ static size_t host_chunk_states(size_t n_perms) {
     return c;
 }
 
+// A big batch in ORDINARY memory.  Page-locking it costs more than moving it (tools/pin_probe.hip on this pool: a first
+// hipHostRegister runs at 18 GB/s, the link moves 47 GB/s each way; hipHostUnregister waits for the device to go idle), while
+// a CPU core copies into page-locked memory at 30 GB/s and four cores at 64 GB/s.  So the caller's pages are never locked:
+// two helper threads copy chunk after chunk into page-locked staging buffers the pipe owns, the chunk pipeline of the
+// page-locked path runs on those, and as many threads copy the results back behind the device -> host copies.  Six
+// slots per direction; a chunk is 2^16 states (10 MiB); thread t of a direction takes chunks t, t + T, ...
+constexpr int kStageSlots = kPipeSlots;              // one staging slot per device chunk buffer and direction
+constexpr size_t kStageChunkStates = (size_t)1 << 16;
+// copy threads per direction (HADES252_STAGE_THREADS, 1 .. 6).  Beside each other the threads get ~15 GB/s apiece
+// (tools/pin_probe.hip: 4 threads 64 GB/s, 8 threads 120 GB/s); the link wants 44 GB/s each way: three per direction.
+static int stage_threads() {
+    static const int v = []() {
+        const char *e = getenv("HADES252_STAGE_THREADS");
+        int t = e ? atoi(e) : 3;
+        return t < 1 ? 1 : (t > kStageSlots ? kStageSlots : t);
+    }();
+    return v;
+}
+
+// what a chunk goes through on the device: the permutation, between the two wire-format conversions for canonical bytes
+static int host_run_kernels(void *d, size_t n, hipStream_t st, bool bytes_format) {
+    if (!bytes_format) return hades252_perm_batch_dev(d, n, st);
+    int r = hades252_from_bytes_dev(d, d, n * 5, nullptr, st);
+    if (r == HADES252_OK) r = hades252_perm_batch_dev(d, n, st);
+    if (r == HADES252_OK) r = hades252_to_bytes_dev(d, d, n * 5, st);
+    return r;
+}
+
+static int perm_batch_host_staged(uint8_t *h, size_t n_perms, HostPipe &pipe, bool bytes_format) {
+    const size_t chunk = kStageChunkStates, cb = chunk * 160;
+    const size_t n_chunks = (n_perms + chunk - 1) / chunk;
+    uint8_t *st_in = (uint8_t *)pipe.stage, *st_out = st_in + (size_t)kStageSlots * cb;
+    struct Shared {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<char> filled, drained;           // chunk c is in its staging slot / has been copied back to the caller
+        size_t h2d_enq = 0, d2h_enq = 0;             // chunks whose copy (and its event) has been enqueued by the main thread
+        bool failed = false;
+        int hip_err = 0;
+    } sh;
+    sh.filled.assign(n_chunks, 0);
+    sh.drained.assign(n_chunks, 0);
+    auto fail = [&](hipError_t e) {
+        {
+            std::lock_guard<std::mutex> lk(sh.mu);
+            sh.failed = true;
+            if (sh.hip_err == 0) sh.hip_err = (int)e;
+        }
+        sh.cv.notify_all();
+    };
+    const int device = pipe.device, kStageThreads = stage_threads();
+    std::vector<std::thread> threads;
+    for (int t = 0; t < kStageThreads; t++) {
+        threads.emplace_back([&, t]() {                                   // caller -> staging
+            (void)hipSetDevice(device);
+            for (size_t c = t; c < n_chunks; c += kStageThreads) {
+                if (c >= (size_t)kStageSlots) {                           // the slot's previous chunk has left for the device
+                    {
+                        std::unique_lock<std::mutex> lk(sh.mu);
+                        sh.cv.wait(lk, [&]() { return sh.failed || sh.h2d_enq > c - kStageSlots; });
+                        if (sh.failed) return;
+                    }
+                    const hipError_t e = F(F_SYNC, hipEventSynchronize(pipe.in_done[c % kStageSlots]));
+                    if (e != hipSuccess) return fail(e);
+                }
+                const size_t off = c * chunk, n = n_perms - off < chunk ? n_perms - off : chunk;
+                memcpy(st_in + (c % kStageSlots) * cb, h + off * 160, n * 160);
+                {
+                    std::lock_guard<std::mutex> lk(sh.mu);
+                    sh.filled[c] = 1;
+                }
+                sh.cv.notify_all();
+            }
+        });
+        threads.emplace_back([&, t]() {                                   // staging -> caller
+            (void)hipSetDevice(device);
+            for (size_t c = t; c < n_chunks; c += kStageThreads) {
+                {
+                    std::unique_lock<std::mutex> lk(sh.mu);
+                    sh.cv.wait(lk, [&]() { return sh.failed || sh.d2h_enq > c; });
+                    if (sh.failed) return;
+                }
+                const hipError_t e = F(F_SYNC, hipEventSynchronize(pipe.out_done[c % kStageSlots]));
+                if (e != hipSuccess) return fail(e);
+                const size_t off = c * chunk, n = n_perms - off < chunk ? n_perms - off : chunk;
+                memcpy(h + off * 160, st_out + (c % kStageSlots) * cb, n * 160);
+                {
+                    std::lock_guard<std::mutex> lk(sh.mu);
+                    sh.drained[c] = 1;
+                }
+                sh.cv.notify_all();
+            }
+        });
+    }
+    int rc = HADES252_OK;
+    hipError_t e = hipSuccess;
+    for (size_t c = 0; c < n_chunks && rc == HADES252_OK; c++) {
+        const int k = (int)(c % kStageSlots);
+        const size_t off = c * chunk, n = n_perms - off < chunk ? n_perms - off : chunk;
+        void *d = (uint8_t *)pipe.buf + (size_t)k * pipe.slot_cap;
+        {
+            std::unique_lock<std::mutex> lk(sh.mu);                       // the chunk is staged; its output slot is free again
+            sh.cv.wait(lk, [&]() { return sh.failed || (sh.filled[c] && (c < (size_t)kStageSlots || sh.drained[c - kStageSlots])); });
+            if (sh.failed) break;
+        }
+        // the device buffer of slot k is free: chunk c - kStageSlots has been copied out of it (drained => out_done passed)
+        if ((e = F(F_MEMCPY, hipMemcpyAsync(d, st_in + (size_t)k * cb, n * 160, hipMemcpyHostToDevice, pipe.s_in))) != hipSuccess) break;
+        if ((e = hipEventRecord(pipe.in_done[k], pipe.s_in)) != hipSuccess) break;
+        {
+            std::lock_guard<std::mutex> lk(sh.mu);
+            sh.h2d_enq = c + 1;
+        }
+        sh.cv.notify_all();
+        if ((e = hipStreamWaitEvent(pipe.s_k, pipe.in_done[k], 0)) != hipSuccess) break;
+        rc = host_run_kernels(d, n, pipe.s_k, bytes_format);
+        if (rc != HADES252_OK) break;
+        if ((e = hipEventRecord(pipe.k_done[k], pipe.s_k)) != hipSuccess) break;
+        if ((e = hipStreamWaitEvent(pipe.s_out, pipe.k_done[k], 0)) != hipSuccess) break;
+        if ((e = F(F_MEMCPY, hipMemcpyAsync(st_out + (size_t)k * cb, d, n * 160, hipMemcpyDeviceToHost, pipe.s_out))) != hipSuccess) break;
+        if ((e = hipEventRecord(pipe.out_done[k], pipe.s_out)) != hipSuccess) break;
+        {
+            std::lock_guard<std::mutex> lk(sh.mu);
+            sh.d2h_enq = c + 1;
+        }
+        sh.cv.notify_all();
+    }
+    if (e != hipSuccess) fail(e);
+    if (rc != HADES252_OK) fail(hipSuccess);
+    for (auto &t : threads) t.join();                                     // the last chunk is back in the caller's buffer
+    if (sh.failed) {
+        if (rc == HADES252_OK) {
+            tl_last_hip_error = sh.hip_err;
+            (void)hipGetLastError();
+            rc = HADES252_ERR_HIP;
+        }
+    }
+    return rc;
+}
+
 // Host batch on the current device.  `bytes_format` inputs have already been validated (all < p).
 //   n <= 256           the kernel works on a page-locked staging buffer over PCIe (no DMA copy at all)
 //   one chunk          copy in, kernel, copy out on one stream
@@ -635,13 +777,7 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
     if (states == nullptr) return HADES252_ERR_INVALID_ARG;
     int rc = check_device();
     if (rc != HADES252_OK) return rc;
-    auto run_kernels = [&](void *d, size_t n, hipStream_t st) {
-        if (!bytes_format) return hades252_perm_batch_dev(d, n, st);
-        int r = hades252_from_bytes_dev(d, d, n * 5, nullptr, st);
-        if (r == HADES252_OK) r = hades252_perm_batch_dev(d, n, st);
-        if (r == HADES252_OK) r = hades252_to_bytes_dev(d, d, n * 5, st);
-        return r;
-    };
+    auto run_kernels = [&](void *d, size_t n, hipStream_t st) { return host_run_kernels(d, n, st, bytes_format); };
     HostPipe pipe;
     if (n_perms <= kPinnedStates) {
         rc = acquire_pipe(0, pipe);
@@ -675,14 +811,28 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
         if (registered) (void)hipHostUnregister(h);
         return code;
     };
-    // Memory the caller has not pinned: page-lock it in place for the duration of the call, so the chunk copies are true
-    // DMA and overlap with the kernels (pageable copies are staged by the runtime at ~15 GB/s).  If registration is
-    // refused the pageable path is used; HADES252_HOST_PIN=0 disables the attempt.
+    // Memory the caller has not pinned.  Several chunks: the batch travels through page-locked staging buffers filled and
+    // drained by helper threads (perm_batch_host_staged) -- the caller's pages are never locked.  One chunk (8 .. 40 MiB):
+    // page-locked in place for the duration of the call, so its two copies are true DMA; if that is refused, or below
+    // 8 MiB, the runtime's own pageable copies.  HADES252_HOST_PIN=0 disables both (plain pageable copies).
     static const bool pin_enabled = []() {
         const char *e = getenv("HADES252_HOST_PIN");
         return !(e && e[0] == '0');
     }();
     if (!assume_pinned && pin_enabled && n_perms * 160 >= ((size_t)8 << 20) && !host_range_pinned(h, n_perms * 160)) {
+        if (n_perms > 2 * kStageChunkStates) {
+            if (pipe.slot_cap < kStageChunkStates * 160) return finish(HADES252_ERR_INVALID_ARG);     // (acquire_pipe sized it)
+            if (pipe.stage == nullptr) {
+                const hipError_t e = F(F_HOSTMALLOC, hipHostMalloc(&pipe.stage, 2 * kStageSlots * kStageChunkStates * 160, hipHostMallocDefault));
+                if (e != hipSuccess) {
+                    pipe.stage = nullptr;
+                    tl_last_hip_error = (int)e;
+                    (void)hipGetLastError();
+                    return finish(HADES252_ERR_HIP);
+                }
+            }
+            return finish(perm_batch_host_staged(h, n_perms, pipe, bytes_format));
+        }
         if (F(F_HOSTREGISTER, hipHostRegister(h, n_perms * 160, hipHostRegisterDefault)) == hipSuccess)
             registered = true;
         else

@@ -108,10 +108,13 @@ int hades252_perm_batch_multi_ex(uint64_t *states, size_t n_perms, int n_workers
 
 /* ---- page-locked host memory for the host-pointer entry points ---------------------------------------
  * The reference's caller holds its states in ordinary memory (`&mut [BlsScalar]`, src/strategies.rs:140).  DMA needs
- * page-locked memory, and locking / unlocking a buffer on every call costs more than moving it.  A caller with a
- * long-lived buffer pins it ONCE: either allocate it here, or register an existing allocation; hades252_perm_batch*
- * recognise such memory (and memory the caller pinned through HIP itself) and go straight to DMA.  Anything else is
- * page-locked per call when >= 8 MiB (environment HADES252_HOST_PIN=0 disables that), else copied as pageable memory.
+ * page-locked memory.  A caller with a long-lived buffer pins it ONCE: either allocate it here, or register an existing
+ * allocation; hades252_perm_batch* recognise such memory (and memory the caller pinned through HIP itself) and go
+ * straight to DMA (93-98 % of the link's bidirectional ceiling from 2^22 states on).  Anything else is never locked
+ * when large: batches of more than 2^17 states travel through page-locked staging buffers of the library, filled and
+ * drained by helper threads (HADES252_STAGE_THREADS per direction, default 3; ~88-92 % of the page-locked rate, at the
+ * price of those CPU cores for the duration of the call); one-chunk batches of 8 MiB and more are page-locked in place
+ * for the call; smaller ones are copied as pageable memory.  HADES252_HOST_PIN=0: plain pageable copies throughout.
  *   hades252_host_alloc      bytes of page-locked host memory, usable from every device; free with hades252_host_free
  *   hades252_host_register   page-lock [p, p + bytes) in place (any alignment); undo with hades252_host_unregister(p)
  *   hades252_host_is_pinned  1 if [p, p + bytes) is page-locked (by either call or through HIP), else 0

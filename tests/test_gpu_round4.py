@@ -163,6 +163,51 @@ def test_perm_batch_under_injected_faults(torch_cuda, H, hades_lib, oracle, n):
     assert H.pool_bytes() <= (1 << 30)
 
 
+def test_big_pageable_batch_goes_through_staging_threads(torch_cuda, H, hades_lib, oracle):
+    """A big batch in ORDINARY memory (more than two 2^16-state chunks): helper threads copy it chunk by chunk into
+    page-locked staging buffers and the results back (perm_batch_host_staged) -- the caller's pages are never locked.
+    Right bits from an unaligned base address and ragged sizes; nothing is locked afterwards; a failing copy, event wait
+    or staging allocation leaves whole states and a working library."""
+    lib = hades_lib
+    for n in (131073, 600000, 4 * 65536, 4 * 65536 + 1, 5 * 65536 - 1):
+        inp = oracle.gen_b(12345 + n, 5 * n)
+        exp = oracle.perm_batch(inp)
+        buf = np.empty(5 * 4 * n + 3, dtype=np.uint64)[3:]         # pageable, base address = 8 (mod 32)
+        buf[:] = inp
+        assert buf.ctypes.data % 32 != 0
+        assert lib.hades252_perm_batch(buf.ctypes.data, n) == 0
+        assert (buf == exp).all(), n
+        assert not H.host_is_pinned(buf)
+    n = 600000                                                     # ten chunks
+    inp = oracle.gen_b(777, 5 * n)
+    exp = oracle.perm_batch(inp)
+    buf = np.empty(5 * 4 * n + 3, dtype=np.uint64)[3:]
+    failures = 0
+    for spec in ("hostmalloc:1", "memcpy:1", "memcpy:4", "memcpy:9", "memcpy:17", "memcpy:20", "sync:1", "sync:3", "sync:11"):
+        if spec.startswith("hostmalloc"):
+            H.trim()                                               # a fresh pipe: the staging buffer is allocated again
+        buf[:] = inp
+        H.fault_inject(spec)
+        rc = lib.hades252_perm_batch(buf.ctypes.data, n)
+        H.fault_inject(None)
+        assert rc in (0, -2), spec
+        failures += rc != 0
+        ok, done = each_state_is_input_or_output(buf, inp, exp)
+        assert ok, spec
+        assert rc != 0 or done == n
+        assert done % 65536 == 0 or done == n, "results come back in whole chunks (%s: %d)" % (spec, done)
+        buf[:] = inp
+        assert lib.hades252_perm_batch(buf.ctypes.data, n) == 0 and (buf == exp).all(), spec
+    assert failures >= 6
+    # the canonical-bytes entry point takes the same road (wire conversions on the device around the permutation)
+    k = 200000
+    torch = torch_cuda
+    b = to_host(H.to_bytes(to_dev(torch, inp[: 20 * k]).view(-1, 4))).view(np.uint8).copy()
+    assert lib.hades252_perm_batch_bytes(b.ctypes.data, k) == 0
+    want = to_host(H.to_bytes(to_dev(torch, exp[: 20 * k]).view(-1, 4))).view(np.uint8)
+    assert (b == want).all()
+
+
 def test_host_callers_under_injected_faults(torch_cuda, H, hades_lib, oracle):
     """hades252_merkle_root / _sponge_hash / _sponge_hash_var: a failing call returns a code, leaves the root untouched,
     and the same call then succeeds."""
