@@ -193,6 +193,7 @@ __device__ __forceinline__ F29 mont_mul_small(const F29 &a, int32_t c) {
 // Input: normalised (limbs 0..7 in [0, 2^29), |top limb| < 2^25: the output of mont_fips / small_mds / to_f29).
 // Output: normalised, value in (-p - 2^227, 2^230).  Column bound: 9 * 2^58 + 2 * 2^58 + carry < 2^62.
 // hades252_amd/_derive.py::lin_table builds the table; tests/test_fast_model.py::mont_lin replays this limb for limb.
+template <int STRIDE = kNL>   // dwords between the columns of the table (9: packed; 12: 16-byte aligned columns in LDS)
 __device__ __forceinline__ F29 mont_lin(const F29 &a, const int32_t *e) {
     int32_t m0 = 0, m1 = 0;
     F29 r;
@@ -207,7 +208,7 @@ __device__ __forceinline__ F29 mont_lin(const F29 &a, const int32_t *e) {
     for (int j = 0; j < kNL; j++) {
         if (j + 1 < kNL) {
 #pragma unroll
-            for (int k = 0; k < kNL; k++) nxt[k] = e[kNL * (j + 1) + k];
+            for (int k = 0; k < kNL; k++) nxt[k] = e[STRIDE * (j + 1) + k];
         }
 #pragma unroll
         for (int k = 0; k < kNL; k++) mac(acc, a.l[k], cur[k]);
@@ -228,6 +229,40 @@ __device__ __forceinline__ F29 mont_lin(const F29 &a, const int32_t *e) {
     mac(acc, m1, NEGP29[kNL - 1]);            // column 9: what is left of m_1 p
     r.l[kNL - 2] = (int32_t)((uint32_t)acc & kMask29);
     acc >>= kLB;
+    r.l[kNL - 1] = (int32_t)acc;
+    return r;
+}
+
+// The same with ONE digit step, for a result that only feeds the linear layer (K_r in a partial round): the table holds
+// E_k = F 2^(29 (k - 8)) mod p, the result is (W - m_0 p) / 2^29, congruent to a F / 2^261 again, in (-1.04 p, 8.6 p) --
+// nine limbs still (top limb < 2^26), and small_mds divides by 2^29 itself, so its output stays below 2^256.  89
+// multiply-adds.  NOT for a value that is squared next (mont_fips wants |value| < 2^257).
+__device__ __forceinline__ F29 mont_lin1(const F29 &a, const int32_t *e) {
+    int32_t m0 = 0;
+    F29 r;
+    int64_t acc = 0;
+    int32_t cur[kNL], nxt[kNL];
+#pragma unroll
+    for (int k = 0; k < kNL; k++) cur[k] = e[k];
+#pragma unroll
+    for (int j = 0; j < kNL; j++) {
+        if (j + 1 < kNL) {
+#pragma unroll
+            for (int k = 0; k < kNL; k++) nxt[k] = e[kNL * (j + 1) + k];
+        }
+#pragma unroll
+        for (int k = 0; k < kNL; k++) mac(acc, a.l[k], cur[k]);
+        if (j >= 1) mac(acc, m0, NEGP29[j]);
+        const int32_t low = (int32_t)((uint32_t)acc & kMask29);
+        if (j == 0)
+            m0 = low;
+        else
+            r.l[j - 1] = low;
+        acc >>= kLB;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < kNL; k++) cur[k] = nxt[k];
+    }
     r.l[kNL - 1] = (int32_t)acc;
     return r;
 }
@@ -297,6 +332,13 @@ __device__ __forceinline__ void fast_round(const int32_t *rec, const int32_t *li
         for (int w = 0; w < 4; w++) add_lazy(st[w], rec + w * kNL);
     }
     add_lazy(st[4], rec + 4 * kNL);
+    if (!full) {
+        // Touch the six 64-byte lines of this round's linear-map table NOW: the column loads of mont_lin, an S-box later,
+        // then hit the scalar cache.  A batch too small to put a second wave on a SIMD cannot hide a scalar-cache miss per
+        // column behind another wave (measured on 4 096 states: 218 us per launch without this, 178 with the product form).
+        const int32_t warm = lin[0] | lin[16] | lin[32] | lin[48] | lin[64] | lin[80];
+        asm volatile("" ::"s"(warm));
+    }
     if (full) {
         st[0] = sbox29(st[0]);
         st[1] = sbox29(st[1]);
@@ -304,7 +346,7 @@ __device__ __forceinline__ void fast_round(const int32_t *rec, const int32_t *li
         st[3] = sbox29(st[3]);
     }
     st[4] = sbox29(st[4]);
-    if (!full) st[4] = mont_lin(st[4], lin);            // back to the common scale: x K_r / Rp as a linear map
+    if (!full) st[4] = mont_lin1(st[4], lin);           // back to the common scale: x K_r / Rp as a linear map
     small_mds(st);
 #pragma unroll
     for (int w = 0; w < 5; w++)

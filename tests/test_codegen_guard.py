@@ -70,7 +70,7 @@ def test_perm_fast_instruction_mix(device_asm):
     # mont_lin's 81 multipliers per partial round arrive as one s_load_dwordx8 + one s_load_dword per column, a column
     # ahead; left to itself the scheduler fetched them dword by dword, each behind its own wait
     singles = len(re.findall(r"\bs_load_dword\b", body))
-    assert singles <= 16, "%d single-dword scalar loads: the column staging of mont_lin got lost" % singles
+    assert singles <= 24, "%d single-dword scalar loads: the column staging of mont_lin got lost" % singles
 
 
 @pytest.mark.parametrize("needle", ["k_perm_fast", "k_sponge", "k_merkle_level_fast", "k_merkle_coop", "k_perm_coop",

@@ -72,11 +72,11 @@ def mont_fips(a, b, sqr=False):
     return r
 
 
-def mont_lin(a, factor):
-    """mont_lin of hades_fast.hpp: a * factor / Rp for a CONSTANT factor as a linear map over the limbs of a (table
-    D.lin_table) + two signed-digit steps.  Same congruence class as mont_fips(a, factor)."""
+def mont_lin(a, factor, steps=2):
+    """mont_lin (steps = 2) / mont_lin1 (steps = 1) of hades_fast.hpp: a * factor / Rp for a CONSTANT factor as a linear
+    map over the limbs of a (table D.lin_table) + `steps` signed-digit steps.  Same congruence class as mont_fips(a, factor)."""
     assert all(0 <= x < (1 << LB) for x in a[:-1]) and abs(a[-1]) < (1 << 25), "input must be normalised"
-    e = D.lin_table(factor)
+    e = D.lin_table(factor, steps)
     assert len(e) == 81 and all(0 <= x < (1 << LB) for x in e)
     m = [0, 0]
     r = [0] * NL
@@ -87,26 +87,30 @@ def mont_lin(a, factor):
             check_acc(acc)
         if j >= 1:
             acc -= m[0] * P29[j]
-        if j >= 2:
+        if j >= 2 and steps == 2:
             acc -= m[1] * P29[j - 1]
         assert abs(acc) < (1 << 62)
         low = acc & MASK
-        if j < 2:
+        if j < steps:
             m[j] = low
             assert (acc - low) % (1 << LB) == 0
         else:
-            r[j - 2] = low
+            r[j - steps] = low
         acc >>= LB
-    acc -= m[1] * P29[NL - 1]
-    r[NL - 2] = acc & MASK
-    acc >>= LB
-    assert -(1 << 25) < acc < (1 << 25)
+    if steps == 2:
+        acc -= m[1] * P29[NL - 1]
+        r[NL - 2] = acc & MASK
+        acc >>= LB
+    assert -(1 << 27) < acc < (1 << 27)
     r[NL - 1] = acc
-    v, steps = val(r), D.LIN_STEPS
+    v = val(r)
     w = sum(a[k] * (factor * pow(2, LB * (k + steps - NL), P) % P) for k in range(NL))
-    assert w - ((1 << (LB * steps)) - 1) * P <= v << (LB * steps) <= w, "result outside (W/2^58 - p, W/2^58]"
+    assert w - ((1 << (LB * steps)) - 1) * P <= v << (LB * steps) <= w, "result outside (W/2^(29 t) - p, W/2^(29 t)]"
     assert (v - val(a) * factor * pow(1 << (LB * NL), -1, P)) % P == 0, "not congruent to a * factor / Rp"
-    assert -P - (1 << 227) < v < (1 << 230)
+    if steps == 2:
+        assert -P - (1 << 227) < v < (1 << 230)
+    else:
+        assert -P - (1 << 251) < v < 9 * P and abs(r[NL - 1]) < (1 << 27)
     return r
 
 
@@ -173,7 +177,7 @@ def fast_perm_model(mont_vals, trace=None):
         if full:
             st = [sbox(x) for x in st]
         else:
-            st[4] = mont_lin(sbox(st[4]), k)
+            st[4] = mont_lin(sbox(st[4]), k, steps=1)    # mont_lin1: one digit step, the linear layer divides again
         st = small_mds(st)
         for x in st:
             assert normalised(x)
@@ -230,8 +234,13 @@ def test_mont_lin_bounds_adversarial():
     for top in ((1 << 25) - 1, -((1 << 25) - 1), 0):
         a = [MASK] * (NL - 1) + [top]
         for factor in (P - 1, D.RP * D.R % P, D.fast_schedule()["final_f"], D.fast_schedule()["part"][30][1], 1):
-            r = mont_lin(a, factor)
-            assert all(0 <= x < (1 << LB) for x in r[:-1])
+            for steps in (2, 1):
+                r = mont_lin(a, factor, steps)
+                assert all(0 <= x < (1 << LB) for x in r[:-1])
+                if steps == 1:                                  # ... and the linear layer takes it as word 4 beside maximal words
+                    big = [MASK] * (NL - 1) + [(1 << 24) - 1]
+                    for row in small_mds([big, big, big, big, r]):
+                        assert normalised(row)
 
 
 def test_model_matches_spec_oracle():

@@ -16,6 +16,10 @@ timeout 300 ./build_tools/residency > gpurun_out/residency_$TAG.txt 2>&1; echo "
 timeout 120 ./build_tools/dfma_proto > gpurun_out/dfma_proto_$TAG.txt 2>&1; echo "dfma rc=$?"
 timeout 900 python tools/time_paths.py > gpurun_out/time_paths_$TAG.txt 2>&1; echo "time_paths rc=$?"
 timeout 300 ./build_tools/host_path_bench callers > gpurun_out/host_callers_$TAG.txt 2>&1; echo "host callers rc=$?"
+timeout 300 ./build_tools/host_path_bench 20 22 24 > gpurun_out/host_path_$TAG.txt 2>&1; echo "host path rc=$?"
+timeout 120 ./build_tools/wire_proto 26 > gpurun_out/wire_proto_$TAG.txt 2>&1; echo "wire_proto rc=$?"
+timeout 120 ./build_tools/copy_proto > gpurun_out/copy_proto_$TAG.txt 2>&1; echo "copy_proto rc=$?"
+timeout 60 ./build_tools/pin_probe > gpurun_out/pin_probe_$TAG.txt 2>&1; echo "pin_probe rc=$?"
 timeout 600 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"
 bash tools/profile_round.sh $TAG > gpurun_out/profile_round_$TAG.log 2>&1; echo "profile rc=$?"
 timeout 600 python bench.py > gpurun_out/bench_${TAG}_after_profile.json 2>> gpurun_out/bench_$TAG.err; echo "bench2 rc=$?"

@@ -189,15 +189,19 @@ def sec_host():
 
 def sec_latency():
     print("== small-call latency: host-pointer call (hades252_perm_batch, default dispatch) and device call + sync per kernel")
-    for n in (1, 4, 64, 256, 1024, 2048, 4096, 16384):
+    for n in (1, 4, 64, 256, 768, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
         host = H.gen_b(5 * n, dev).cpu().numpy().view(np.uint64).reshape(-1).copy()
         s = H.ScalarStrategy(0)
         ts = []
         for _ in range(7):
             ts.append(timed(lambda: s.perm(host), reps=50))
-        print("n=%-5d host call (in + kernel + out), default dispatch: median %8.1f us  min %8.1f us" % (n, sorted(ts)[3] * 1e6, min(ts) * 1e6))
+        print("n=%-5d host call (in + kernel + out), default dispatch (%s): median %8.1f us  min %8.1f us"
+              % (n, H.kernel_name(0, n), sorted(ts)[3] * 1e6, min(ts) * 1e6))
         buf = H.gen_b(5 * n, dev)
-        for k, name in ((4, "lanes (one state per wave)"), (3, "coop (five waves per state)"), (2, "fast (one state per lane)")):
+        for k, name in ((4, "lanes (one state per wave)"), (5, "rows (four states per wave)"), (3, "coop (five waves per state)"),
+                        (2, "fast (one state per lane)")):
+            if (k == 4 and n > 4096) or (k == 5 and n > 16384):
+                continue
             sk = H.ScalarStrategy(k)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev = []
