@@ -22,6 +22,8 @@ __device__ const LanesTables d_lanes = {HADES_LANES_ROUND_INIT, HADES_COOP_FINAL
 // the same arithmetic under the throughput kernel's schedule: one state per 16-lane row (rows_perm)
 __device__ const LanesTables d_rows = {HADES_ROWS_ROUND_INIT, HADES_FAST_FINAL_F, HADES_FAST_MDS_SMALL, HADES_P29,
                                         HADES_P29, HADES_NEG_PINV29};
+// ... and K_r of its 59 partial rounds as the per-lane constants of lane_lin (the linear map by the row)
+__device__ const uint32_t d_rows_klin[59][kNL][16] = HADES_ROWS_KLIN_INIT;
 // trace kernel: U_r with mont(X_after_round_r, U_r) = x * 2^256
 __device__ const int32_t d_trace_lin[67][kLinRow] = HADES_FAST_TRACE_LIN_INIT;        // as linear maps (mont_lin)
 // ... + D_r: the partial-round constants of words 0..3 that the shipped schedule defers (hades_fast.hpp item 5)

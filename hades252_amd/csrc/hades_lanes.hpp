@@ -214,6 +214,42 @@ __device__ __forceinline__ uint32_t lane_mont_mul(const LaneConsts &K, uint32_t 
 }
 __device__ __forceinline__ uint32_t lane_mont_sqr(const LaneConsts &K, uint32_t a) { return lane_mont_mul(K, a, a); }
 
+// a F / 2^261 (mod p) for a CONSTANT F, as a linear map by the row (the lane form of mont_lin, hades_fast.hpp): the table
+// holds E_k = F 2^(29 (k - 7)) mod p as PER-LANE constants (e[k]: lane j = limb j of E_k, zero for j >= 9), so
+//   W = sum_k a_k E_k           lane j sums column j: 9 multiply-adds with a_k broadcast by the row
+//   M = W p' mod 2^58           two limbs: 2 multiply-adds (W, and W shifted by one lane)
+//   R = (W + M p) / 2^58        2 multiply-adds (m_0, m_1 broadcast; pk = limb k of p per lane, pk1 = the same shifted)
+// 13 multiply-adds, ~12 DPP moves and three carry steps instead of the 28 / ~45 / three of lane_mont_mul_n: about half
+// a product.  After the last carry step the two low limbs are an exact multiple of 2^58 (w_0 = 0, w_1 = c 2^29), c is
+// carried into limb 2 and the row moves down two lanes.  Same operand / result bounds as lane_mont_mul_n.
+// tests/test_fast_model.py::lane_lin replays this statement by statement.
+__device__ __forceinline__ uint32_t lane_lin(const LaneConsts &K, uint32_t a, const uint32_t (&e)[kNL], uint32_t pk, uint32_t pk1) {
+    const int lane = threadIdx.x & 15;
+    uint64_t acc = 0;
+    umac(acc, row_bcast<0>(a), e[0]);
+    umac(acc, row_bcast<1>(a), e[1]);
+    umac(acc, row_bcast<2>(a), e[2]);
+    umac(acc, row_bcast<3>(a), e[3]);
+    umac(acc, row_bcast<4>(a), e[4]);
+    umac(acc, row_bcast<5>(a), e[5]);
+    umac(acc, row_bcast<6>(a), e[6]);
+    umac(acc, row_bcast<7>(a), e[7]);
+    umac(acc, row_bcast<8>(a), e[8]);
+    uint32_t c16, c17;
+    const uint32_t t = carry_split(acc, c16, c17);
+    uint64_t am = 0;
+    umac(am, t, K.pinv[0]);
+    umac(am, row_shr<1>(t), K.pinv[1]);
+    const uint32_t m = carry_split(am, c16, c17);                    // lanes 0 and 1 count
+    acc = (uint64_t)t;
+    umac(acc, row_bcast<0>(m), pk);
+    umac(acc, row_bcast<1>(m), pk1);
+    uint32_t w = carry_split(acc, c16, c17);
+    const uint32_t z = lane == 1 ? w >> kLB : 0;
+    w += row_shr<1>(z);
+    return row_shl<2>(w);
+}
+
 // v^5 / Rp^4 for N independent values side by side
 template <int N>
 __device__ __forceinline__ void lane_sbox_n(const LaneConsts &K, uint32_t (&v)[N]) {
@@ -529,7 +565,8 @@ struct RowsLds {                // per wave
 
 // in: lane 5 s + w (s < 4, w < 5) holds word w of the wave's state s as a BlsScalar (other lanes ignored);
 // out: the permuted words, fully reduced, in the same lanes.
-__device__ __forceinline__ Fr rows_perm(const LanesTables *T, RowsLds &L, const Fr &in) {
+// klin: HADES_ROWS_KLIN_INIT, [59][9][16]: K_r of partial round 4 + i as the per-lane constants of lane_lin
+__device__ __forceinline__ Fr rows_perm(const LanesTables *T, const uint32_t (*klin)[kNL][16], RowsLds &L, const Fr &in) {
     const int lane = threadIdx.x & 63, row = lane >> 4, k = lane & 15;
     LaneConsts K;
 #pragma unroll
@@ -542,7 +579,7 @@ __device__ __forceinline__ Fr rows_perm(const LanesTables *T, RowsLds &L, const 
     for (int i = 0; i < 5; i++)
 #pragma unroll
         for (int j = 0; j < 5; j++) cm[i][j] = T->mds[i][j];
-    const uint32_t pk = T->p16[k];
+    const uint32_t pk = T->p16[k], pk1 = row_shr<1>(pk);
     if (lane < 20) {
         const F29 f = to_f29(in);
         const int s_in = lane / 5, w_in = lane - 5 * s_in;
@@ -580,23 +617,33 @@ __device__ __forceinline__ Fr rows_perm(const LanesTables *T, RowsLds &L, const 
 #pragma unroll
         for (int j = 0; j < 5; j++) asm volatile("" : "+v"(w[j]));
     };
-    auto partial_round = [&]() {
+    // the linear-map constants of K_r, one partial round ahead like the round constants (a per-lane load: lane k = limb k)
+    const uint32_t *kl = &klin[0][0][0] + k;
+    uint32_t ek[kNL], en[kNL];
+#pragma unroll
+    for (int i = 0; i < kNL; i++) ek[i] = kl[16 * i];
+    auto partial_round = [&](bool last) {
         rec += 64;
         uint32_t n[5], nk;
         fetch(n, nk);
+        if (!last) kl += kNL * 16;
+#pragma unroll
+        for (int i = 0; i < kNL; i++) en[i] = kl[16 * i];
         const uint32_t v5 = lane_sbox(K, w[4] + c[4]);
-        w[4] = lane_mont_mul(K, v5, ck);                             // back to the common scale
+        w[4] = lane_lin(K, v5, ek, pk, pk1);                         // back to the common scale: v5 K_r / Rp
         linear();
 #pragma unroll
         for (int j = 0; j < 5; j++) c[j] = n[j];
         ck = nk;
+#pragma unroll
+        for (int i = 0; i < kNL; i++) ek[i] = en[i];
 #pragma unroll
         for (int j = 0; j < 5; j++) asm volatile("" : "+v"(w[j]));
     };
 #pragma unroll 1
     for (int r = 0; r < 4; r++) full_round();
 #pragma unroll 1
-    for (int r = 4; r < 63; r++) partial_round();
+    for (int r = 4; r < 63; r++) partial_round(r == 62);
 #pragma unroll 1
     for (int r = 63; r < 67; r++) full_round();
 #pragma unroll

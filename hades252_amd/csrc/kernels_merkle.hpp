@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(kRowsWaves *kWave) k_merkle_rows(const uint8_t
         const size_t c = rec * ARITY + (word - 1);
         in = c < n_children ? load_word(children + c * 32) : load_pad(pad);
     }
-    const Fr out = rows_perm(&d_rows, L[wave], in);
+    const Fr out = rows_perm(&d_rows, d_rows_klin, L[wave], in);
     if (mine && word == out_idx) store_word(parents + rec * 32, out);
 }
 
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(kRowsWaves *kWave) k_merkle_update_rows(const 
     Fr in = zero_word();
     if (mine && word == 0) in = tag;
     if (mine && word >= 1 && word <= ARITY) in = update_child<ARITY>(children, n_children, parent, word - 1, pad);
-    const Fr out = rows_perm(&d_rows, L[wave], in);
+    const Fr out = rows_perm(&d_rows, d_rows_klin, L[wave], in);
     if (mine && word == out_idx) store_word(parents + parent * 32, out);
 }
 
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(kRowsWaves *kWave) k_merkle_verify_rows(const 
         idx /= ARITY;
         const Fr in = fr_select(word == 0, tag, fr_select(word == pos + 1, node, sib));
         if (l + 1 < depth) sib = sibling(l + 1, idx);
-        const Fr out = rows_perm(&d_rows, L[wave], in);
+        const Fr out = rows_perm(&d_rows, d_rows_klin, L[wave], in);
 #pragma unroll
         for (int i = 0; i < 8; i++) node.l[i] = __shfl(out.l[i], src < kWave ? src : 0, kWave);
     }

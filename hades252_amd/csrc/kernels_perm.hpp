@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(kRowsWaves *kWave) k_perm_rows(uint8_t *states
     const bool mine = rows_role(n, rec, word);
     uint8_t *p = states + (mine ? rec : 0) * 160 + word * 32;
     const Fr in = mine ? load_word(p) : zero_word();
-    const Fr out = rows_perm(&d_rows, L[wave], in);
+    const Fr out = rows_perm(&d_rows, d_rows_klin, L[wave], in);
     if (mine) store_word(p, out);
 }
 

@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(kRowsWaves *kWave) k_sponge_rows(const uint8_t
     for (uint64_t t = 0; t < trips; t++) {
         if (word >= 1) st = fr_add(st, nxt);
         nxt = block_word(t + 1);
-        st = rows_perm(&d_rows, L[wave], st);
+        st = rows_perm(&d_rows, d_rows_klin, L[wave], st);
         if (t + 1 == g.blocks) dig = st;
     }
     if (mine && word == 1) store_word(digests + me * 32, dig);
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(kRowsWaves *kWave) k_sponge_absorb_rows(uint8_
     for (int t = 0; t < blocks_each; t++) {
         if (word >= 1) st = fr_add(st, nxt);
         if (mine && t + 1 < blocks_each) nxt = load_word(blk + (size_t)(t + 1) * 128);
-        st = rows_perm(&d_rows, L[wave], st);
+        st = rows_perm(&d_rows, d_rows_klin, L[wave], st);
     }
     if (mine) store_word(p, st);
 }

@@ -562,6 +562,38 @@ def lane_mont_mul(a, b):
     return out
 
 
+def lane_lin(a, factor):
+    """lane_lin of hades_lanes.hpp: a * factor / 2^261 (mod p) for a CONSTANT factor as a linear map by the row:
+    W = sum_k a_k E_k with E_k = factor 2^(29 (k - 7)) mod p as per-lane constants (lane j: limb j), then the two-limb form
+    of the row's Montgomery step: M = W p' mod 2^58 (two multiply-adds), R = (W + M p) / 2^58 (two more)."""
+    assert all(0 <= x <= LANE_IN_MAX for x in a) and lane_val(a) < (1 << 258)
+    e = [D.to_limbs29(factor * pow(2, LB * (k + D.LIN_STEPS - NL), P) % P) + [0] * 7 for k in range(NL)]
+    acc = [0] * 16
+    for k in range(NL):
+        acc = [u64(c + x * y) for c, x, y in zip(acc, row_bcast(a, k), e[k])]
+    t, c16, c17 = carry_split(acc)
+    assert c16[15] == 0 and c17[15] == 0
+    wv = sum(x << (LB * k) for k, x in enumerate(t))
+    assert wv == sum(a[k] * val(e[k][:NL]) for k in range(NL))
+    am = [u64(x * PINV29[0] + y * PINV29[1]) for x, y in zip(t, row_shr(t, 1))]
+    m, _, _ = carry_split(am)
+    mv = m[0] + (m[1] << LB)
+    assert (mv - wv * val(PINV29)) % (1 << (2 * LB)) == 0 and mv < (1 << 59) + (1 << 30)      # M == W p' (mod 2^58)
+    pk = P29 + [0] * 7
+    acc = [u64(x + p0 * q0 + p1 * q1) for x, p0, q0, p1, q1 in zip(t, row_bcast(m, 0), pk, row_bcast(m, 1), row_shr(pk, 1))]
+    w, c16, c17 = carry_split(acc)
+    assert c16[15] == 0 and c17[15] == 0
+    assert w[0] == 0 and w[1] & MASK == 0, "the low two limbs cancel to a multiple of 2^58"
+    z = [w[k] >> LB if k == 1 else 0 for k in range(16)]
+    w = [u32(x + y) for x, y in zip(w, row_shr(z, 1))]
+    out = row_shl(w, 2)
+    r = lane_val(out)
+    assert r << (2 * LB) == wv + mv * P, "R = (W + M p) / 2^58 exactly"
+    assert (r - lane_val(a) * factor * pow(D.RP, -1, P)) % P == 0
+    assert r < (wv >> (2 * LB)) + 2 * P + (P >> 20) and all(x <= LANE_IN_MAX for x in out) and out[NL - 1] < (1 << 26)
+    return out
+
+
 def lane_sbox(v):
     v2 = lane_mont_mul(v, v)
     v4 = lane_mont_mul(v2, v2)
@@ -628,6 +660,9 @@ def test_lanes_product_bounds_adversarial():
         for b in rows[:9]:
             r = lane_mont_mul(a, b)
             assert lane_val(r) % P == lane_val(a) * lane_val(b) * pow(D.RP, -1, P) % P
+    for a in rows:                                        # the linear map by the row on the same operands
+        for factor in (P - 1, 1, D.fast_schedule()["part"][17][1], D.fast_schedule()["part"][62][1]):
+            lane_lin(a, factor)
     # linear layer at its maxima
     big = [LANE_IN_MAX] * (NL - 1) + [(1 << 26) - 1] + [0] * 7             # the result bound of a product
     for i in range(5):
@@ -661,7 +696,7 @@ def rows_perm_model(mont_vals):
             a, k = sch["part"][r]
             assert all(a[w] == 0 for w in range(4))
             v5 = lane_sbox([u32(x + y) for x, y in zip(st[4], row_of(a[4]))])
-            nxt = st[:4] + [lane_mont_mul(v5, row_of(k))]
+            nxt = st[:4] + [lane_lin(v5, k)]                      # K_r as a linear map by the row (round 4)
         st = [lane_mds_row(D.MDS_SMALL[i], nxt) for i in range(5)]
     return [finalize_model(x[:NL], sch["final_f"]) for x in st]
 
