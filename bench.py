@@ -47,10 +47,12 @@ sys.path.insert(0, ROOT)
 ALGO_BYTES_PER_PERM = 320
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak, MI355X_MICROARCH.md
 # The binding resource is VALU issue.  Per-permutation instruction counts of k_perm_fast: static ISA count
-#  = rocprofv3 SQ_INSTS_VALU / SQ_WAVES = 88 702 per wave (profiles/r2/pmc_summary.json).
-MADS_PER_PERM = 99 * 387 + 64 * 153 + 67 * 265      # 64-bit multiply-adds
-OPS64_PER_PERM = MADS_PER_PERM + 9400               # + 64-bit shifts: same issue class
-OPS32_PER_PERM = 88700 - OPS64_PER_PERM             # 32-bit ops
+#  = rocprofv3 SQ_INSTS_VALU / SQ_WAVES = 83 945 per wave (profiles/r4/pmc_summary.json; 88 702
+# before the constant products became linear maps).
+MADS_PER_PERM = 99 * 387 + 59 * 89 + 5 * 97 + 67 * 265       # 64-bit multiply-adds: S-boxes, K_r, FINAL_F, linear layers
+SHIFTS_PER_PERM = 17 * 297 + 9 * 59 + 10 * 5 + 45 * 67       # 64-bit arithmetic shifts, one per column: same issue class
+OPS64_PER_PERM = MADS_PER_PERM + SHIFTS_PER_PERM
+OPS32_PER_PERM = 83945 - OPS64_PER_PERM                      # 32-bit ops
 N_SIMD = 1024
 PEAK_CLOCK_HZ = 2.4e9
 # Issue model: a wave64 instruction occupies its SIMD-16 for 4 cycles when 64-bit, 2 cycles when 32-bit
@@ -432,7 +434,7 @@ def main():
                      "kernel": kernel_name, "kernel_ms": kernel_ms_max,
                      "algorithmic_bytes_per_perm": ALGO_BYTES_PER_PERM,
                      "note": "HBM traffic equals the algorithmic bytes; the kernel is VALU-issue bound "
-                             "(~89 k instructions per 320 B), see valu_issue and DESIGN.md"},
+                             "(~84 k instructions per 64 x 320 B), see valu_issue and DESIGN.md"},
         "digest": ["%016x" % d for d in digest],
         "parity_vs_cpu_sample": all_ok,
         "parity_sample": "%d states of every rank's shard, read back after the %d timed + warm-up launches of the timed "
