@@ -28,8 +28,8 @@ DEPS = ["hades252.hip", "fr32.hpp", "staging.hpp", "hades_literal.hpp", "hades_f
 # what the dominant kernel (k_perm_fast) is made of: profiles recorded for it stay valid while these are unchanged
 PERM_FAST_DEPS = ["fr32.hpp", "staging.hpp", "hades_fast.hpp", "k_perm_fast.hpp"]
 # ... plus these tables of hades_constants.inc (other kernels' tables may change without touching k_perm_fast)
-PERM_FAST_TABLES = ("HADES_FAST_L", "HADES_FAST_MDS_SMALL", "HADES_NEG_P29", "HADES_TWO_P29", "HADES_FAST_ROUND_INIT",
-                    "HADES_FAST_FINAL_F")
+PERM_FAST_TABLES = ("HADES_FAST_L", "HADES_FAST_MDS_SMALL", "HADES_NEG_P29", "HADES_TWO_P29", "HADES_P29", "HADES_FAST_ROUND_INIT",
+                    "HADES_FAST_FINAL_F", "HADES_FAST_LIN_INIT", "HADES_FAST_FINAL_LIN")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-pthread",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
