@@ -640,6 +640,19 @@ static int stage_threads() {
     return v;
 }
 
+static bool host_pin_enabled() {
+    static const bool v = []() {
+        const char *e = getenv("HADES252_HOST_PIN");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+static int pipe_ensure_stage(HostPipe &p) {
+    if (p.stage != nullptr) return HADES252_OK;
+    HIP_TRY(F(F_HOSTMALLOC, hipHostMalloc(&p.stage, 2 * kStageSlots * kStageChunkStates * 160, hipHostMallocDefault)));
+    return HADES252_OK;
+}
+
 // what a chunk goes through on the device: the permutation, between the two wire-format conversions for canonical bytes
 static int host_run_kernels(void *d, size_t n, hipStream_t st, bool bytes_format) {
     if (!bytes_format) return hades252_perm_batch_dev(d, n, st);
@@ -772,7 +785,7 @@ static int perm_batch_host_staged(uint8_t *h, size_t n_perms, HostPipe &pipe, bo
 // storing its results over PCIe itself runs every chunk in lockstep (compute, then a burst of stores): 29-37 GB/s;
 // DMA both ways: 43.6 GB/s = 92 % of the 47.4 GB/s the link gives bare copies in both directions at once.
 static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, bool bytes_format,
-                                             bool assume_pinned = false) {
+                                             bool never_register = false) {
     if (n_perms == 0) return HADES252_OK;
     if (states == nullptr) return HADES252_ERR_INVALID_ARG;
     int rc = check_device();
@@ -815,28 +828,19 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
     // drained by helper threads (perm_batch_host_staged) -- the caller's pages are never locked.  One chunk (8 .. 40 MiB):
     // page-locked in place for the duration of the call, so its two copies are true DMA; if that is refused, or below
     // 8 MiB, the runtime's own pageable copies.  HADES252_HOST_PIN=0 disables both (plain pageable copies).
-    static const bool pin_enabled = []() {
-        const char *e = getenv("HADES252_HOST_PIN");
-        return !(e && e[0] == '0');
-    }();
-    if (!assume_pinned && pin_enabled && n_perms * 160 >= ((size_t)8 << 20) && !host_range_pinned(h, n_perms * 160)) {
+    if (host_pin_enabled() && n_perms * 160 >= ((size_t)8 << 20) && !host_range_pinned(h, n_perms * 160)) {
         if (n_perms > 2 * kStageChunkStates) {
             if (pipe.slot_cap < kStageChunkStates * 160) return finish(HADES252_ERR_INVALID_ARG);     // (acquire_pipe sized it)
-            if (pipe.stage == nullptr) {
-                const hipError_t e = F(F_HOSTMALLOC, hipHostMalloc(&pipe.stage, 2 * kStageSlots * kStageChunkStates * 160, hipHostMallocDefault));
-                if (e != hipSuccess) {
-                    pipe.stage = nullptr;
-                    tl_last_hip_error = (int)e;
-                    (void)hipGetLastError();
-                    return finish(HADES252_ERR_HIP);
-                }
-            }
+            rc = pipe_ensure_stage(pipe);
+            if (rc != HADES252_OK) return finish(rc);
             return finish(perm_batch_host_staged(h, n_perms, pipe, bytes_format));
         }
-        if (F(F_HOSTREGISTER, hipHostRegister(h, n_perms * 160, hipHostRegisterDefault)) == hipSuccess)
-            registered = true;
-        else
-            (void)hipGetLastError();
+        if (!never_register) {
+            if (F(F_HOSTREGISTER, hipHostRegister(h, n_perms * 160, hipHostRegisterDefault)) == hipSuccess)
+                registered = true;
+            else
+                (void)hipGetLastError();
+        }
     }
 #define TRY_FIN(expr)                                \
     do {                                             \
@@ -968,19 +972,10 @@ int hades252_perm_batch_multi_ex(uint64_t *states, size_t n_perms, int n_workers
     if (n_workers <= 0) n_workers = avail;
     if (n_workers > (virt ? 64 : avail)) return HADES252_ERR_INVALID_ARG;
     if ((size_t)n_workers > n_perms) n_workers = (int)n_perms;
-    // Page-lock the caller's buffer ONCE for all devices (shards share boundary pages: per-shard registration
-    // would overlap and be refused for some shards, by a race); portable = visible to every device.
-    bool registered = false;
-    bool pinned = host_range_pinned(states, n_perms * 160);
-    if (!pinned) {
-        const char *e = getenv("HADES252_HOST_PIN");
-        if (!(e && e[0] == '0') && n_perms * 160 >= ((size_t)8 << 20)) {
-            if (F(F_HOSTREGISTER, hipHostRegister(states, n_perms * 160, hipHostRegisterPortable)) == hipSuccess)
-                registered = true;
-            else
-                (void)hipGetLastError();
-        }
-    }
+    // Nothing is page-locked here.  A buffer the caller pinned goes straight to DMA on every device; ordinary memory
+    // travels through each worker's own staging threads (shards share boundary pages, so a worker must never register
+    // its sub-range; one registration of the whole buffer up front -- round 3 -- runs at 18 GB/s against the 47 GB/s each
+    // way of EVERY device's link).
     std::vector<int> rcs(n_workers, HADES252_OK);
     std::vector<int> hip_errs(n_workers, 0);
     std::vector<std::thread> threads;
@@ -994,14 +989,11 @@ int hades252_perm_batch_multi_ex(uint64_t *states, size_t n_perms, int n_workers
                 return;
             }
             pin_thread_near_device(virt ? g % avail : g);
-            // registered or pinned by the caller: skip the per-shard attempt; neither (refused / disabled): also skip
-            // it -- a sub-range attempt would only repeat the refusal -- and use the pageable path
-            rcs[g] = perm_batch_host_on_current_device(states + 20 * b, e - b, false, true);
+            rcs[g] = perm_batch_host_on_current_device(states + 20 * b, e - b, false, /*never_register=*/true);
             hip_errs[g] = tl_last_hip_error;
         });
     }
     for (auto &t : threads) t.join();
-    if (registered) (void)hipHostUnregister(states);
     for (int g = 0; g < n_workers; g++)
         if (rcs[g] != HADES252_OK) {
             tl_last_hip_error = hip_errs[g];
@@ -1750,20 +1742,107 @@ static int pipe_ensure_aux(HostPipe &p, size_t bytes) {
     return HADES252_OK;
 }
 
-// page-lock a big input the caller has not pinned (read-only use); returns whether it has to be unlocked afterwards
-static bool pin_input_for_call(const void *h, size_t bytes, unsigned flags = hipHostRegisterDefault) {
-    const char *e = getenv("HADES252_HOST_PIN");
-    if ((e && e[0] == '0') || bytes < ((size_t)8 << 20) || host_range_pinned(h, bytes)) return false;
-    if (F(F_HOSTREGISTER, hipHostRegister(const_cast<void *>(h), bytes, flags)) == hipSuccess) return true;
-    (void)hipGetLastError();
-    return false;
-}
+// Uploads from ORDINARY memory for the one-shot callers (Merkle root, sponge): helper threads copy the input, chunk by
+// chunk, into the pipe's page-locked staging slots and the chunk copies to the device start from there -- the caller's
+// pages are never locked, for the reasons given at perm_batch_host_staged (a first hipHostRegister runs at 18 GB/s and
+// only LOOKS free when a benchmark reuses its buffer: the driver caches the pinning).
+class StagedSource {
+  public:
+    static size_t slot_bytes() { return 2 * kStageChunkStates * 160; }      // kStageSlots of them fill the staging buffer
+    // stages [h, h + bytes) in chunks of chunk_bytes <= slot_bytes(); pipe.stage must exist
+    StagedSource(const uint8_t *h, size_t bytes, size_t chunk_bytes, HostPipe &pipe)
+        : h_(h), bytes_(bytes), cb_(chunk_bytes), pipe_(pipe), n_chunks_((bytes + chunk_bytes - 1) / chunk_bytes) {
+        filled_.assign(n_chunks_, 0);
+        const int nt = stage_threads();
+        for (int t = 0; t < nt; t++) threads_.emplace_back([this, t, nt]() { run(t, nt); });
+    }
+    ~StagedSource() { stop(); }
+    // staged address of chunk c (blocks until it is there); nullptr if a helper thread failed
+    const uint8_t *wait(size_t c) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&]() { return failed_ || filled_[c]; });
+        return failed_ ? nullptr : (const uint8_t *)pipe_.stage + (c % kStageSlots) * slot_bytes();
+    }
+    // the copy of chunk c out of its slot has been enqueued on pipe.s_in and pipe.in_done[c % kStageSlots] recorded behind it
+    void enqueued(size_t c) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            enq_ = c + 1;
+        }
+        cv_.notify_all();
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            failed_ = failed_ || enq_ < n_chunks_;       // an early exit of the caller releases the helpers
+        }
+        cv_.notify_all();
+        for (auto &t : threads_)
+            if (t.joinable()) t.join();
+    }
+    int hip_error() const { return hip_err_; }
+
+  private:
+    void run(int t, int nt) {
+        (void)hipSetDevice(pipe_.device);
+        for (size_t c = t; c < n_chunks_; c += nt) {
+            if (c >= (size_t)kStageSlots) {               // the slot's previous chunk has left for the device
+                {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&]() { return failed_ || enq_ > c - kStageSlots; });
+                    if (failed_) return;
+                }
+                const hipError_t e = F(F_SYNC, hipEventSynchronize(pipe_.in_done[c % kStageSlots]));
+                if (e != hipSuccess) {
+                    {
+                        std::lock_guard<std::mutex> lk(mu_);
+                        failed_ = true;
+                        hip_err_ = (int)e;
+                    }
+                    cv_.notify_all();
+                    return;
+                }
+            }
+            const size_t off = c * cb_, n = bytes_ - off < cb_ ? bytes_ - off : cb_;
+            memcpy((uint8_t *)pipe_.stage + (c % kStageSlots) * slot_bytes(), h_ + off, n);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                filled_[c] = 1;
+            }
+            cv_.notify_all();
+        }
+    }
+    const uint8_t *h_;
+    size_t bytes_, cb_;
+    HostPipe &pipe_;
+    size_t n_chunks_, enq_ = 0;
+    std::vector<char> filled_;
+    bool failed_ = false;
+    int hip_err_ = 0;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::thread> threads_;
+};
 
 struct HostCall {                 // releases what a one-shot host call holds, whichever way it ends
     HostPipe pipe;
-    const void *registered = nullptr;
+    StagedSource *src = nullptr;  // upload through staging threads (input in ordinary memory)
     bool have_pipe = false;
+    // decides how the input travels: through staging threads when it is big, in ordinary memory and HADES252_HOST_PIN
+    // allows; else straight from the caller's memory (DMA if page-locked, the runtime's pageable copy otherwise).
+    // *chunk_bytes is clamped to a staging slot in the first case.  Call after acquire_pipe.
+    int plan_upload(const void *h, size_t bytes, size_t *chunk_bytes, size_t granule) {
+        if (!host_pin_enabled() || bytes < ((size_t)8 << 20) || host_range_pinned(h, bytes)) return HADES252_OK;
+        int rc = pipe_ensure_stage(pipe);
+        if (rc != HADES252_OK) return rc;
+        size_t cb = *chunk_bytes < StagedSource::slot_bytes() ? *chunk_bytes : StagedSource::slot_bytes();
+        cb -= cb % granule;
+        *chunk_bytes = cb;
+        src = new StagedSource((const uint8_t *)h, bytes, cb, pipe);
+        return HADES252_OK;
+    }
     int finish(int code) {
+        if (src) src->stop();
         if (have_pipe) {
             (void)hipStreamSynchronize(pipe.s_in);
             (void)hipStreamSynchronize(pipe.s_k);
@@ -1772,8 +1851,11 @@ struct HostCall {                 // releases what a one-shot host call holds, w
             release_pipe(pipe, code != HADES252_OK);
             have_pipe = false;
         }
-        if (registered) (void)hipHostUnregister(const_cast<void *>(registered));
-        registered = nullptr;
+        if (src) {
+            if (code == HADES252_ERR_HIP && tl_last_hip_error == 0) tl_last_hip_error = src->hip_error();
+            delete src;
+            src = nullptr;
+        }
         return code;
     }
 };
@@ -1788,10 +1870,8 @@ struct HostCall {                 // releases what a one-shot host call holds, w
         }                                              \
     } while (0)
 
-// no_pin: the caller (hades252_merkle_root_multi) has already dealt with page-locking for the whole input -- a
-// sub-range attempt here would race with the neighbouring workers over shared boundary pages
 static int merkle_root_host(const uint64_t *leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
-                            const uint64_t *pad, uint64_t root[4], bool no_pin) {
+                            const uint64_t *pad, uint64_t root[4]) {
     const int depth = hades252_merkle_depth(n_leaves, arity);
     if (leaves == nullptr || root == nullptr || tag_mont == nullptr || depth < 1 || out_idx < 0 || out_idx >= 5)
         return HADES252_ERR_INVALID_ARG;
@@ -1809,6 +1889,12 @@ static int merkle_root_host(const uint64_t *leaves, size_t n_leaves, int arity, 
     if (rc != HADES252_OK) return rc;
     call.have_pipe = true;
     HostPipe &pp = call.pipe;
+    {
+        size_t cbytes = chunk * 32;
+        rc = call.plan_upload(leaves, n_leaves * 32, &cbytes, (size_t)32 * arity);
+        if (rc != HADES252_OK) return call.finish(rc);
+        chunk = cbytes / 32;
+    }
     rc = pipe_ensure_aux(pp, head + n1 * 32 + scratch);
     if (rc != HADES252_OK) return call.finish(rc);
     uint8_t *d_pad = (uint8_t *)pp.aux, *d_root = d_pad + (size_t)depth * 32, *d_l1 = d_pad + head;
@@ -1816,7 +1902,6 @@ static int merkle_root_host(const uint64_t *leaves, size_t n_leaves, int arity, 
     const Fr tag = fr_from_u64(tag_mont);
     if (pad != nullptr) TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d_pad, pad, (size_t)depth * 32, hipMemcpyHostToDevice, pp.s_k)));
     const uint8_t *dp = pad != nullptr ? d_pad : nullptr;
-    if (!no_pin && pin_input_for_call(leaves, n_leaves * 32)) call.registered = leaves;
     const uint8_t *h = (const uint8_t *)leaves;
     const size_t n_chunks = (n_leaves + chunk - 1) / chunk;
     for (size_t c = 0; c < n_chunks; c++) {                           // level 1, chunk by chunk behind the copies
@@ -1824,8 +1909,11 @@ static int merkle_root_host(const uint64_t *leaves, size_t n_leaves, int arity, 
         const size_t off = c * chunk, n = n_leaves - off < chunk ? n_leaves - off : chunk;
         uint8_t *d = (uint8_t *)pp.buf + (size_t)k * pp.slot_cap;
         if (c >= (size_t)kPipeSlots) TRY_CALL(call, F(F_SYNC, hipEventSynchronize(pp.k_done[k])));   // chunk c - kPipeSlots is hashed
-        TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d, h + off * 32, n * 32, hipMemcpyHostToDevice, pp.s_in)));
+        const uint8_t *from = call.src ? call.src->wait(c) : h + off * 32;
+        if (from == nullptr) return call.finish(HADES252_ERR_HIP);
+        TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d, from, n * 32, hipMemcpyHostToDevice, pp.s_in)));
         TRY_CALL(call, hipEventRecord(pp.in_done[k], pp.s_in));
+        if (call.src) call.src->enqueued(c);
         TRY_CALL(call, hipStreamWaitEvent(pp.s_k, pp.in_done[k], 0));
         launch_merkle_any(arity, d, n, n1 == 1 ? d_root : d_l1 + (off / arity) * 32, tag, out_idx, dp, pp.s_k);
         TRY_CALL(call, hipGetLastError());
@@ -1845,7 +1933,7 @@ static int merkle_root_host(const uint64_t *leaves, size_t n_leaves, int arity, 
 
 int hades252_merkle_root(const uint64_t *leaves, size_t n_leaves, int arity, const uint64_t tag_mont[4], int out_idx,
                          const uint64_t *pad, uint64_t root[4]) {
-    return merkle_root_host(leaves, n_leaves, arity, tag_mont, out_idx, pad, root, false);
+    return merkle_root_host(leaves, n_leaves, arity, tag_mont, out_idx, pad, root);
 }
 
 int hades252_sponge_hash(const uint64_t *msgs, size_t n_msgs, size_t msg_len, const uint64_t capacity_mont[4],
@@ -1866,9 +1954,14 @@ int hades252_sponge_hash(const uint64_t *msgs, size_t n_msgs, size_t msg_len, co
     if (rc != HADES252_OK) return rc;
     call.have_pipe = true;
     HostPipe &pp = call.pipe;
+    if (msg_bytes && msg_bytes <= StagedSource::slot_bytes()) {
+        size_t cbytes = chunk * msg_bytes;
+        rc = call.plan_upload(msgs, n_msgs * msg_bytes, &cbytes, msg_bytes);
+        if (rc != HADES252_OK) return call.finish(rc);
+        chunk = cbytes / msg_bytes;
+    }
     rc = pipe_ensure_aux(pp, (size_t)kPipeSlots * chunk * 32);                           // digests of the chunks in flight
     if (rc != HADES252_OK) return call.finish(rc);
-    if (msg_bytes && pin_input_for_call(msgs, n_msgs * msg_bytes)) call.registered = msgs;
     const uint8_t *h = (const uint8_t *)msgs;
     uint8_t *out = (uint8_t *)digests;
     const size_t n_chunks = (n_msgs + chunk - 1) / chunk;
@@ -1877,8 +1970,13 @@ int hades252_sponge_hash(const uint64_t *msgs, size_t n_msgs, size_t msg_len, co
         const size_t off = c * chunk, n = n_msgs - off < chunk ? n_msgs - off : chunk;
         uint8_t *d = (uint8_t *)pp.buf + (size_t)k * pp.slot_cap, *dd = (uint8_t *)pp.aux + (size_t)k * chunk * 32;
         if (c >= (size_t)kPipeSlots) TRY_CALL(call, F(F_SYNC, hipEventSynchronize(pp.out_done[k])));
-        if (msg_bytes) TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d, h + off * msg_bytes, n * msg_bytes, hipMemcpyHostToDevice, pp.s_in)));
+        if (msg_bytes) {
+            const uint8_t *from = call.src ? call.src->wait(c) : h + off * msg_bytes;
+            if (from == nullptr) return call.finish(HADES252_ERR_HIP);
+            TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d, from, n * msg_bytes, hipMemcpyHostToDevice, pp.s_in)));
+        }
         TRY_CALL(call, hipEventRecord(pp.in_done[k], pp.s_in));
+        if (call.src) call.src->enqueued(c);
         TRY_CALL(call, hipStreamWaitEvent(pp.s_k, pp.in_done[k], 0));
         rc = sponge_launch(d, nullptr, nullptr, n, msg_len, capacity_mont, pad_mode, dd, pp.s_k, n * msg_len, nullptr, nullptr);
         if (rc != HADES252_OK) return call.finish(rc);
@@ -1910,9 +2008,7 @@ int hades252_merkle_root_multi(const uint64_t *leaves, size_t n_leaves, int arit
     if ((size_t)n_workers > n_sub) n_workers = (int)n_sub;
     if (n_sub == 1) return hades252_merkle_root(leaves, n_leaves, arity, tag_mont, out_idx, nullptr, root);
     const size_t per = n_leaves / n_sub;
-    // once for all workers (their sub-ranges share boundary pages) and for every device; refused or disabled: the
-    // workers use pageable copies, none of them tries again on its own sub-range
-    const bool registered = pin_input_for_call(leaves, n_leaves * 32, hipHostRegisterPortable);
+    // (nothing is page-locked here: leaves in ordinary memory travel through each worker's staging threads)
     std::vector<uint64_t> sub(n_sub * 4);
     std::vector<int> rcs(n_workers, HADES252_OK), hip_errs(n_workers, 0);
     std::vector<std::thread> threads;
@@ -1927,12 +2023,11 @@ int hades252_merkle_root_multi(const uint64_t *leaves, size_t n_leaves, int arit
             pin_thread_near_device(virt ? g % avail : g);
             const size_t b = n_sub * (size_t)g / n_workers, e = n_sub * (size_t)(g + 1) / n_workers;
             for (size_t t = b; t < e && rcs[g] == HADES252_OK; t++)
-                rcs[g] = merkle_root_host(leaves + t * per * 4, per, arity, tag_mont, out_idx, nullptr, &sub[t * 4], true);
+                rcs[g] = merkle_root_host(leaves + t * per * 4, per, arity, tag_mont, out_idx, nullptr, &sub[t * 4]);
             hip_errs[g] = tl_last_hip_error;
         });
     }
     for (auto &t : threads) t.join();
-    if (registered) (void)hipHostUnregister(const_cast<uint64_t *>(leaves));
     for (int g = 0; g < n_workers; g++)
         if (rcs[g] != HADES252_OK) {
             tl_last_hip_error = hip_errs[g];
@@ -1966,8 +2061,25 @@ int hades252_sponge_hash_var(const uint64_t *scalars, size_t n_scalars, const ui
     if (rc != HADES252_OK) return call.finish(rc);
     uint8_t *d_pool = (uint8_t *)pp.aux, *d_off = d_pool + pool_b, *d_len = d_off + idx_b, *d_dig = d_len + idx_b;
     uint8_t *d_scr = d_dig + dig_b, *d_bad = d_scr + scr_b;
-    if (n_scalars && pin_input_for_call(scalars, n_scalars * 32)) call.registered = scalars;
-    if (n_scalars) TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d_pool, scalars, n_scalars * 32, hipMemcpyHostToDevice, pp.s_k)));
+    if (n_scalars) {                                                 // the pool: through the staging threads when it is big
+        size_t cbytes = StagedSource::slot_bytes();                  // and in ordinary memory, else one copy
+        rc = call.plan_upload(scalars, n_scalars * 32, &cbytes, 32);
+        if (rc != HADES252_OK) return call.finish(rc);
+        if (call.src) {
+            const size_t total = n_scalars * 32, n_chunks = (total + cbytes - 1) / cbytes;
+            for (size_t c = 0; c < n_chunks; c++) {
+                const size_t off = c * cbytes, n = total - off < cbytes ? total - off : cbytes;
+                const uint8_t *from = call.src->wait(c);
+                if (from == nullptr) return call.finish(HADES252_ERR_HIP);
+                TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d_pool + off, from, n, hipMemcpyHostToDevice, pp.s_in)));
+                TRY_CALL(call, hipEventRecord(pp.in_done[c % kPipeSlots], pp.s_in));
+                call.src->enqueued(c);
+            }
+            TRY_CALL(call, hipStreamWaitEvent(pp.s_k, pp.in_done[(n_chunks - 1) % kPipeSlots], 0));
+        } else {
+            TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d_pool, scalars, n_scalars * 32, hipMemcpyHostToDevice, pp.s_k)));
+        }
+    }
     TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d_off, offsets, n_msgs * 8, hipMemcpyHostToDevice, pp.s_k)));
     TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d_len, lengths, n_msgs * 8, hipMemcpyHostToDevice, pp.s_k)));
     TRY_CALL(call, hipMemsetAsync(d_bad, 0, 4, pp.s_k));

@@ -240,6 +240,70 @@ def test_host_callers_under_injected_faults(torch_cuda, H, hades_lib, oracle):
             assert (H.sponge_hash_host(m, 3000, 6, CAP, 1).reshape(-1) == dig_exp).all()
 
 
+def test_big_inputs_of_the_one_shot_callers_travel_through_staging(torch_cuda, H, hades_lib, oracle, kat):
+    """Merkle root / sponge / variable-length sponge on big inputs in ORDINARY memory (>= 8 MiB): uploaded through the
+    staging threads (StagedSource), nothing of the caller's page-locked; right results, also with ragged last chunks and
+    from an unaligned base; a failing copy or event wait gives a return code, leaves the outputs alone where the header
+    says so, and the next call is right."""
+    lib = hades_lib
+    n = 4 ** 10 + 4 ** 9 + 12345                                 # 42 MiB of leaves, ragged tree, ragged chunks
+    base = oracle.gen_b(9, n + 1)
+    leaves = base[4:]                                            # base address = 32 B past an allocation start
+    want = oracle.merkle_tree(leaves, 4, TAG4, 1)[-1]
+    assert (H.merkle_root_host(leaves, 4, TAG4, 1) == want).all()
+    assert not H.host_is_pinned(leaves)
+    assert hex(int_of(H.merkle_root_host(oracle.gen_b(0, 4 ** 10), 4, TAG4, 1))) == kat["merkle4_full_size"][str(4 ** 10)]["root"]
+    fails = 0
+    for spec in ("memcpy:1", "memcpy:2", "memcpy:3", "sync:1", "sync:2", "hostmalloc:1"):
+        if spec.startswith("hostmalloc"):
+            H.trim()
+        root = np.full(4, 0xABCDEF, dtype=np.uint64)
+        H.fault_inject(spec)
+        rc = lib.hades252_merkle_root(leaves.ctypes.data, n, 4, H._tag_arr(TAG4), 1, None, root.ctypes.data)
+        H.fault_inject(None)
+        assert rc in (0, -2), spec
+        fails += rc != 0
+        assert (root == (want if rc == 0 else 0xABCDEF)).all(), spec
+        assert (H.merkle_root_host(leaves, 4, TAG4, 1) == want).all(), spec
+    assert fails >= 4
+    # fixed-length sponge: 2^18 messages of 5 scalars (40 MiB)
+    nm, ln = 1 << 18, 5
+    msgs = oracle.gen_b(31, nm * ln)
+    dig = oracle.sponge(msgs, ln, CAP, 1)
+    assert (H.sponge_hash_host(msgs, nm, ln, CAP, 1).reshape(-1) == dig).all()
+    # variable-length sponge: a 24 MiB pool, messages of 0 .. 9 scalars anywhere in it
+    rng = np.random.default_rng(5)
+    pool = oracle.gen_b(77, 750000)
+    lens = rng.integers(0, 10, size=60000).astype(np.uint64)
+    offs = rng.integers(0, 750000 - 10, size=60000).astype(np.uint64)
+    got, bad = H.sponge_hash_var_host(pool, offs, lens, CAP, 1)
+    assert bad == 0 and (np.asarray(got).reshape(-1) == oracle.sponge_var(pool, offs, lens, CAP, 1)).all()
+    for spec in ("memcpy:2", "sync:1"):
+        H.fault_inject(spec)
+        out = np.zeros(4 * 60000, dtype=np.uint64)
+        rc = lib.hades252_sponge_hash_var(pool.ctypes.data, 750000, offs.ctypes.data, lens.ctypes.data, 60000, H._tag_arr(CAP), 1,
+                                          out.ctypes.data, None)
+        H.fault_inject(None)
+        assert rc in (0, -2), spec
+        got, bad = H.sponge_hash_var_host(pool, offs, lens, CAP, 1)
+        assert bad == 0 and (np.asarray(got).reshape(-1) == oracle.sponge_var(pool, offs, lens, CAP, 1)).all()
+
+
+def test_multi_entry_points_on_ordinary_memory(torch_cuda, H, hades_lib, oracle):
+    """hades252_perm_batch_multi_ex / hades252_merkle_root_multi on a big buffer in ORDINARY memory: no registration of
+    the whole buffer any more; every worker stages its own shard (shards share boundary pages).  2, 3 and 8 virtual
+    workers on this one device."""
+    n = 900000                                                   # 144 MB: 8 shards of 18 MB -> each through its staging threads
+    inp = oracle.gen_b(2024, 5 * n)
+    exp = oracle.perm_batch(inp)
+    for w in (2, 3, 8):
+        buf = np.empty(20 * n + 1, dtype=np.uint64)[1:]
+        buf[:] = inp
+        H.perm_multi(buf, w, virtual=True)
+        assert (buf == exp).all(), w
+        assert not H.host_is_pinned(buf)
+
+
 def test_multi_worker_failure_is_reported_and_survivable(torch_cuda, H, hades_lib, oracle):
     """One worker of hades252_perm_batch_multi_ex cannot select its device: the call reports it, the other workers' shards
     are whole states (input or output), nothing hangs, and the next call is right."""
