@@ -98,7 +98,9 @@ int hades252_perm_batch_bytes(uint8_t *states, size_t n_perms);
 int hades252_perm_batch_dev(void *d_states, size_t n_perms, void *stream);
 int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int kernel);
 /* Host batch sharded over the first n_devices GPUs (contiguous ranges, one host thread and
- * pipe per device, no collective).  n_devices <= 0 means all visible devices. */
+ * pipe per device, no collective).  n_devices <= 0 means all visible devices.  A buffer the caller page-locked
+ * (hades252_host_alloc / _register: portable, every device sees it) goes straight to DMA on every link; ordinary memory
+ * travels through each worker's staging threads (3 + 3 CPU threads per worker). */
 int hades252_perm_batch_multi(uint64_t *states, size_t n_perms, int n_devices);
 /* Same with n_workers host threads; flags = HADES252_MULTI_VIRTUAL maps worker g to device g % (visible devices)
  * instead of device g, so that n_workers may exceed the device count (up to 64): a one-GPU box then runs the code
@@ -167,7 +169,8 @@ int hades252_fault_inject(const char *spec);
 
 /* ---- the callers of perm, host memory in, host memory out -------------------------------------------------
  * One-shot forms of the Merkle root and the fixed-length sponge for data that lives in host memory (page-locked or not,
- * as for hades252_perm_batch): the leaves / messages travel to the device in chunks while the previous chunk is being
+ * as for hades252_perm_batch: big inputs in ordinary memory go through the library's staging threads, nothing of the
+ * caller's is page-locked): the leaves / messages travel to the device in chunks while the previous chunk is being
  * hashed (the first tree level / the sponge itself), only 32 bytes per tree / message travel back.
  *   hades252_merkle_root   leaves: n_leaves x 4 u64 (Montgomery limbs); pad: NULL or depth x 4 u64 (the padding table of
  *                          hades252_merkle_root_pad_dev, host memory); semantics of hades252_merkle_root_pad_dev
