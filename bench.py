@@ -28,7 +28,8 @@ Also in the line:
   secondary     outside `value`: BASELINE.json configs[3] (arity-4 Merkle tree over 2^24 leaves: tree
                 time, nodes/s, its own roofline with 160 B per node), `single_perm` (ONE permutation: device
                 and host-call latency), `sponge_chain` (one message of 1000 blocks: us per dependent
-                permutation), and `host_path`: the entry point a
+                permutation), `wire_format` (to_bytes / from_bytes at 2^26 scalars against the HBM roofline), and
+                `host_path`: the entry point a
                 Rust `Strategy::perm` binds (`hades252_perm_batch`: host memory in, host memory out,
                 PCIe-inclusive) on 2^22 states against this box's measured bidirectional copy ceiling.
 `--workload merkle` times the tree build itself as the step (development; the driver runs the default).
@@ -234,6 +235,34 @@ def merkle_record(H, torch, device, log_leaves: int, reps: int = 5):
             "golden": "tests/golden/kat.json merkle4_full_size (C oracle, %d permutations)" % nodes,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_node": MERKLE_BYTES_PER_NODE}}, leaves
+
+
+def wire_format_record(H, torch, device, log_n=26):
+    """SURVEY section 8(f) row 3: BlsScalar::to_bytes / from_bytes on the device, 2^log_n scalars (2 GiB in + 2 GiB out at
+    26: far beyond the 256 MB Infinity Cache), HIP events, median of 5.  Pure HBM streaming kernels: their roofline IS the
+    HBM one, 64 algorithmic bytes per scalar (counter traffic = algorithmic x 1.000: profiles/r4/wire_bw_last_session.txt)."""
+    n = 1 << log_n
+    limbs = H.gen_b(n, device)
+    out = torch.empty_like(limbs)
+    canon = H.to_bytes(limbs)
+    rec = {"workload": "2^%d scalars per launch, 32 B in + 32 B out each" % log_n}
+    for name, fn in (("to_bytes", lambda: H.to_bytes(limbs, out)), ("from_bytes", lambda: H.from_bytes(canon, out))):
+        fn()
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            ms.append(a.elapsed_time(b))
+        med = sorted(ms)[2]
+        ach = 64.0 * n / (med * 1e-3) / 1e9
+        rec[name] = {"ms": med, "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_scalar": 64}}
+    rec["round_trip_exact"] = bool(torch.equal(out, limbs))          # from_bytes(to_bytes(x)) == x on all 2^log_n scalars
+    return rec
 
 
 def sponge_chain_record(H, torch, device, blocks=1000):
@@ -465,6 +494,8 @@ def main():
             torch.cuda.empty_cache()
             sec["single_perm"] = single_perm_record(H, torch, device)
             sec["sponge_chain"] = sponge_chain_record(H, torch, device)
+            sec["wire_format"] = wire_format_record(H, torch, device)
+            torch.cuda.empty_cache()
             sec["host_path"] = host_path_record(22)
         except Exception as e:                       # secondary records never take the headline down
             sec["error"] = repr(e)

@@ -37,6 +37,12 @@ def test_bench_single_and_two_ranks_agree():
     sp = one["secondary"]["single_perm"]
     assert 20 < sp["device_us_median"] < 150 and sp["device_us_min"] <= sp["host_call_us_median"] < 400
     assert 20 < one["secondary"]["sponge_chain"]["us_per_block"] < 150
+    assert mk["root_matches_golden"] is True                          # the timed tree == the CPU oracle's committed root
+    wf = one["secondary"]["wire_format"]
+    assert wf["round_trip_exact"] is True
+    for k in ("to_bytes", "from_bytes"):
+        assert wf[k]["roofline"]["bound"] == "hbm" and 0.3 < wf[k]["roofline"]["frac"] < 1.0
+    assert 0 < hp["pageable_ms"] < 3 * hp["ms"]                       # ordinary memory on fresh pages: staging threads
     assert one["config"]["kernel"] == "k_perm_fast" and "valu_issue" in one and "frac_of_measured" not in one["valu_issue"]
     assert one["n_gpus"] == 1 and one["parity_vs_cpu_sample"] is True
     assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1
