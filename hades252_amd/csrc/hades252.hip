@@ -488,17 +488,22 @@ static void release_pipe(HostPipe p, bool failed = false) {
         destroy_pipe(p);
         return;
     }
-    void *free_aux = nullptr, *free_buf = nullptr;
+    void *free_aux = nullptr, *free_buf = nullptr, *free_stage = nullptr;
     bool destroy = false;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         size_t held = 0;
-        int count = 0;
+        int count = 0, staged = 0;
         for (const HostPipe &q : g_pool)
             if (q.device == p.device) {
                 held += pipe_bytes(q);
                 count++;
+                staged += q.stage != nullptr;
             }
+        if (p.stage != nullptr && staged >= 2) {                               // at most two 120 MiB page-locked staging
+            free_stage = p.stage;                                              // buffers stay cached per device
+            p.stage = nullptr;
+        }
         if (count >= kPoolMaxPipes) {
             destroy = true;
         } else {
@@ -518,7 +523,8 @@ static void release_pipe(HostPipe p, bool failed = false) {
     if (destroy) destroy_pipe(p);
     if (free_aux) (void)hipFree(free_aux);
     if (free_buf) (void)hipFree(free_buf);
-    if (free_aux || free_buf) (void)hipGetLastError();
+    if (free_stage) (void)hipHostFree(free_stage);
+    if (free_aux || free_buf || free_stage) (void)hipGetLastError();
 }
 
 // slot_bytes == 0: a small call (needs the page-locked staging buffer, no device buffer)

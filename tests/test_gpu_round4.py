@@ -304,6 +304,32 @@ def test_multi_entry_points_on_ordinary_memory(torch_cuda, H, hades_lib, oracle)
         assert not H.host_is_pinned(buf)
 
 
+def test_concurrent_big_callers_on_ordinary_memory(torch_cuda, H, hades_lib, oracle):
+    """Four host threads, each with its own big batch in ordinary memory, at the same time: every call gets its own pipe,
+    staging buffer and helper threads; results right, the pool stays within its budget and keeps at most two staging
+    buffers per device."""
+    n = 300000
+    inps = [oracle.gen_b(100 + t, 5 * n) for t in range(4)]
+    exps = [oracle.perm_batch(x) for x in inps]
+    bufs = [x.copy() for x in inps]
+    rcs = [None] * 4
+
+    def work(t):
+        rcs[t] = hades_lib.hades252_perm_batch(bufs[t].ctypes.data, n)
+    for _ in range(2):
+        for t in range(4):
+            bufs[t][:] = inps[t]
+        ts = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        for th in ts:
+            th.start()
+        for th in ts:
+            th.join()
+        assert rcs == [0] * 4
+        for t in range(4):
+            assert (bufs[t] == exps[t]).all(), t
+    assert H.pool_bytes() <= (1 << 30)
+
+
 def test_multi_worker_failure_is_reported_and_survivable(torch_cuda, H, hades_lib, oracle):
     """One worker of hades252_perm_batch_multi_ex cannot select its device: the call reports it, the other workers' shards
     are whole states (input or output), nothing hangs, and the next call is right."""
