@@ -178,5 +178,11 @@ inline void sponge_hash(const BlsScalar *msgs, std::size_t n_msgs, std::size_t m
                                reinterpret_cast<std::uint64_t *>(digests)), "sponge_hash");
 }
 
+// What the library caches (pipes: streams, chunk buffers, staging memory) and which kernel a batch size gets.
+inline void trim() { check(hades252_trim(), "trim"); }
+inline std::size_t pool_bytes() { return hades252_pool_bytes(); }
+inline int kernel_for(std::size_t n_perms) { return hades252_kernel_for(n_perms); }
+inline const char *kernel_name(int kernel, std::size_t n_perms) { return hades252_kernel_name(kernel, n_perms); }
+
 }  // namespace dusk_hades
 #endif
