@@ -206,6 +206,12 @@ def test_big_pageable_batch_goes_through_staging_threads(torch_cuda, H, hades_li
     assert lib.hades252_perm_batch_bytes(b.ctypes.data, k) == 0
     want = to_host(H.to_bytes(to_dev(torch, exp[: 20 * k]).view(-1, 4))).view(np.uint8)
     assert (b == want).all()
+    # ... and rejects a batch with ONE value >= p deep inside it up front (the check runs on several threads), untouched
+    b2 = to_host(H.to_bytes(to_dev(torch, inp[: 20 * k]).view(-1, 4))).view(np.uint8).copy()
+    pos = 32 * (5 * k - 12345)
+    b2[pos:pos + 32] = np.frombuffer(S.P.to_bytes(32, "little"), dtype=np.uint8)
+    keep = b2.copy()
+    assert lib.hades252_perm_batch_bytes(b2.ctypes.data, k) == -3 and (b2 == keep).all()
 
 
 def test_host_callers_under_injected_faults(torch_cuda, H, hades_lib, oracle):
