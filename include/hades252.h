@@ -333,7 +333,7 @@ int hades252_merkle4_root_dev(const void *d_leaves, size_t n_leaves, void *d_scr
  * A sponge is a chain of dependent permutations per message: batches of up to 1 024 messages (all sponge entry points,
  * hades252_sponge_absorb_dev included) run one message per WAVE on the low-latency arithmetic, ~50 us per block -- ONE
  * long message hashes at the speed of a CPU core (52 us per block) instead of 160 us per block; up to 4 096 four messages per
- * wave (~85 us per block), up to 16 384 five waves per message (~105 us); larger batches run one message per lane (throughput). */
+ * wave (~80 us per block), up to 16 384 five waves per message (~105 us); larger batches run one message per lane (throughput). */
 int hades252_sponge_hash_dev(const void *d_msgs, size_t n_msgs, size_t msg_len, const uint64_t capacity_mont[4],
                              int pad_mode, void *d_digests, void *stream);
 /* Variable-length batch: message i = d_scalars[d_offsets[i] .. d_offsets[i] + d_lengths[i]) (offsets and
