@@ -98,15 +98,13 @@ static int callers() {
             th = std::min(th, now() - t0);
         }
         bool ok = memcmp(want, got, 32) == 0;
-        {                                                         // ordinary memory the driver already knows (a reused Vec)
-            std::vector<uint64_t> plain(lv, lv + n * 4);
-            for (int rep = 0; rep < 3; rep++) {
-                double t0 = now();
-                HK(hades252_merkle_root(plain.data(), n, 4, tag, 1, nullptr, got));
-                tp = std::min(tp, now() - t0);
-            }
-            ok = ok && memcmp(want, got, 32) == 0;
+        std::vector<uint64_t> plain(lv, lv + n * 4);              // ordinary memory the driver already knows (a reused Vec)
+        for (int rep = 0; rep < 3; rep++) {
+            double t0 = now();
+            HK(hades252_merkle_root(plain.data(), n, 4, tag, 1, nullptr, got));
+            tp = std::min(tp, now() - t0);
         }
+        ok = ok && memcmp(want, got, 32) == 0;
         printf("merkle root, arity 4, 2^%d leaves in HOST memory: page-locked %.3f ms, pageable %.3f ms;  device-resident %.3f ms, "
                "bare upload of the leaves %.3f ms (%.1f GB/s);  roots equal: %s\n",
                logn, th * 1e3, tp * 1e3, td * 1e3, tc * 1e3, bytes / tc / 1e9, ok ? "yes" : "NO");
@@ -144,7 +142,7 @@ static int callers() {
         HK(hades252_host_free(ms)); HK(hades252_host_free(dg));
         CK(hipFree(d)); CK(hipFree(d_dig));
     }
-    // last (mapping and unmapping half a gigabyte leaves the process's small calls ~80 us slower for a while): the Merkle
+    // last: the Merkle
     // root of leaves in ordinary memory THE DRIVER HAS NEVER SEEN -- fresh pages for every repetition
     for (int logn : {20, 24}) {
         const size_t n = (size_t)1 << logn, bytes = n * 32;
