@@ -383,7 +383,8 @@ def test_pool_is_bounded_and_trim_gives_memory_back(torch_cuda, H, hades_lib, or
     leaves = oracle.gen_b(0, n)
     exp = hex(int_of(H.merkle_root_host(leaves, 4, TAG4, 1)))
     held = H.pool_bytes()
-    assert 0 < held <= (1 << 30)
+    budget = int(os.environ.get("HADES252_POOL_MAX_BYTES", 1 << 30))
+    assert held <= budget and (held > 0 or budget < (1 << 28))
     # many concurrent large calls: every one gets its own pipe; what returns to the pool stays under the budget
     out = [None] * 6
 
