@@ -378,7 +378,9 @@ def main():
     dev_index = 0 if args.single_device else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # (HADES252_BENCH_FORCE_DIST=1: initialise the process group at world size 1 too -- how the RCCL bookkeeping path, barrier /
+    #  max / gather / digest sum on GPU tensors, is exercised on a one-GPU box: tests/test_bench_contract.py)
+    if world > 1 or os.environ.get("HADES252_BENCH_FORCE_DIST") == "1":
         try:
             sharding.init_process_group(args.dist_backend)
         except Exception as e:                     # no silent fallback, no re-exec: say why and leave with a failure

@@ -83,3 +83,24 @@ def test_bench_reports_the_kernel_that_ran():
         assert tiny["config"]["kernel"] == name and tiny["parity_vs_cpu_sample"] is True
     mk = run([sys.executable, "bench.py", "--workload", "merkle", "--steps", "3"])
     assert mk["unit"] == "nodes/s" and mk["roofline"]["algorithmic_bytes_per_node"] == 160 and mk["value"] > 1e8
+
+
+def test_bench_bookkeeping_over_rccl_at_world_size_one():
+    """The RCCL path of the bookkeeping collectives (barrier with device_ids, all_reduce MAX / MIN / SUM and all_gather on GPU
+    tensors: hades252_amd/sharding.py) has only ever run over gloo in the 2-rank tests; a one-GPU box can still run it for
+    real at world size 1: bench.py under a torchrun-style environment with backend nccl (= RCCL)."""
+    env = {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+           "MASTER_PORT": str(29900 + os.getpid() % 90), "HADES252_BENCH_FORCE_DIST": "1"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        one = run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--perms-per-gpu", str(1 << 18),
+                   "--cpu-sample", "4096", "--no-secondary", "--dist-backend", "nccl"])
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert one["n_gpus"] == 1 and one["parity_vs_cpu_sample"] is True and len(one["per_gpu"]["kernel_ms_per_rank"]) == 1
+    assert len(one["digest"]) == 4 and one["value"] > 0
