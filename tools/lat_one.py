@@ -8,7 +8,7 @@ from hades252_amd import strategy as H
 
 P = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 buf = H.gen_b(5, "cuda")
-for k in (4, 3, 2):
+for k in (4, 5, 3, 2):          # lanes, rows, five waves, one state per lane
     s = H.ScalarStrategy(k)
     for _ in range(200):
         s.perm(buf)
