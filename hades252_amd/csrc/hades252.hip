@@ -52,9 +52,9 @@ static thread_local int tl_last_hip_error = 0;
 // F(site, call): the call, unless the hook is armed for `site` and this is its nth occurrence -- then the error the
 // runtime would have returned.  Disarmed: one relaxed load and a compare.
 enum FaultSite { F_NONE = -1, F_MALLOC, F_HOSTMALLOC, F_HOSTREGISTER, F_MEMCPY, F_STREAMCREATE, F_EVENTCREATE, F_SYNC,
-                 F_WORKER, F_N_SITES };
+                 F_WORKER, F_THREAD, F_N_SITES };
 static const char *const kFaultNames[F_N_SITES] = {"malloc", "hostmalloc", "hostregister", "memcpy", "streamcreate",
-                                                   "eventcreate", "sync", "worker"};
+                                                   "eventcreate", "sync", "worker", "thread"};
 static std::atomic<int> g_fault_site{F_NONE};
 static std::atomic<long> g_fault_nth{0};
 static int fault_arm(const char *spec) {
@@ -82,6 +82,18 @@ static inline bool fault_hit(int site) {
     return true;
 }
 #define F(site, call) (fault_hit(site) ? (site == F_MALLOC || site == F_HOSTMALLOC ? hipErrorOutOfMemory : hipErrorUnknown) : (call))
+
+// std::thread's constructor throws when the system refuses another thread; no exception may cross the C boundary.
+template <class Fn>
+static bool spawn(std::vector<std::thread> &threads, Fn &&fn) {
+    if (fault_hit(F_THREAD)) return false;
+    try {
+        threads.emplace_back(std::forward<Fn>(fn));
+        return true;
+    } catch (...) {
+        return false;
+    }
+}
 
 // device buffers are moved with 16-byte vector loads/stores
 static inline bool misaligned(const void *p) { return ((uintptr_t)p & 15u) != 0; }
@@ -692,8 +704,9 @@ static int perm_batch_host_staged(uint8_t *h, size_t n_perms, HostPipe &pipe, bo
     };
     const int device = pipe.device, kStageThreads = stage_threads();
     std::vector<std::thread> threads;
-    for (int t = 0; t < kStageThreads; t++) {
-        threads.emplace_back([&, t]() {                                   // caller -> staging
+    bool spawned = true;
+    for (int t = 0; t < kStageThreads && spawned; t++) {
+        spawned = spawn(threads, [&, t]() {                               // caller -> staging
             (void)hipSetDevice(device);
             for (size_t c = t; c < n_chunks; c += kStageThreads) {
                 if (c >= (size_t)kStageSlots) {                           // the slot's previous chunk has left for the device
@@ -714,7 +727,7 @@ static int perm_batch_host_staged(uint8_t *h, size_t n_perms, HostPipe &pipe, bo
                 sh.cv.notify_all();
             }
         });
-        threads.emplace_back([&, t]() {                                   // staging -> caller
+        spawned = spawned && spawn(threads, [&, t]() {                    // staging -> caller
             (void)hipSetDevice(device);
             for (size_t c = t; c < n_chunks; c += kStageThreads) {
                 {
@@ -735,8 +748,8 @@ static int perm_batch_host_staged(uint8_t *h, size_t n_perms, HostPipe &pipe, bo
         });
     }
     int rc = HADES252_OK;
-    hipError_t e = hipSuccess;
-    for (size_t c = 0; c < n_chunks && rc == HADES252_OK; c++) {
+    hipError_t e = spawned ? hipSuccess : hipErrorOutOfMemory;           // a missing helper would leave chunks unstaged
+    for (size_t c = 0; c < n_chunks && rc == HADES252_OK && spawned; c++) {
         const int k = (int)(c % kStageSlots);
         const size_t off = c * chunk, n = n_perms - off < chunk ? n_perms - off : chunk;
         void *d = (uint8_t *)pipe.buf + (size_t)k * pipe.slot_cap;
@@ -921,11 +934,13 @@ static bool all_canonical_mt(const uint8_t *bytes, size_t n_scalars) {
     if (nt == 1) return all_canonical(bytes, n_scalars);
     std::atomic<bool> ok{true};
     std::vector<std::thread> ts;
-    for (size_t t = 0; t < nt; t++)
-        ts.emplace_back([&, t]() {
+    for (size_t t = 0; t < nt; t++) {
+        auto slice = [&, t]() {
             const size_t b = n_scalars * t / nt, e = n_scalars * (t + 1) / nt;
             if (!all_canonical(bytes + 32 * b, e - b)) ok.store(false);
-        });
+        };
+        if (!spawn(ts, slice)) slice();                                  // no thread to be had: on this one
+    }
     for (auto &t : ts) t.join();
     return ok.load();
 }
@@ -1002,7 +1017,10 @@ int hades252_perm_batch_multi_ex(uint64_t *states, size_t n_perms, int n_workers
     std::vector<int> hip_errs(n_workers, 0);
     std::vector<std::thread> threads;
     for (int g = 0; g < n_workers; g++) {
-        threads.emplace_back([&, g]() {
+        rcs[g] = HADES252_ERR_HIP;                                       // stands if the thread cannot be started
+        hip_errs[g] = (int)hipErrorOutOfMemory;
+        spawn(threads, [&, g]() {
+            rcs[g] = HADES252_OK;
             size_t b = n_perms * (size_t)g / n_workers, e = n_perms * (size_t)(g + 1) / n_workers;
             hipError_t err = F(F_WORKER, hipSetDevice(virt ? g % avail : g));
             if (err != hipSuccess) {
@@ -1776,7 +1794,16 @@ class StagedSource {
         : h_(h), bytes_(bytes), cb_(chunk_bytes), pipe_(pipe), n_chunks_((bytes + chunk_bytes - 1) / chunk_bytes) {
         filled_.assign(n_chunks_, 0);
         const int nt = stage_threads();
-        for (int t = 0; t < nt; t++) threads_.emplace_back([this, t, nt]() { run(t, nt); });
+        for (int t = 0; t < nt; t++)
+            if (!spawn(threads_, [this, t, nt]() { run(t, nt); })) {
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    failed_ = true;                        // wait() then returns nullptr: the call fails, nothing hangs
+                    hip_err_ = (int)hipErrorOutOfMemory;
+                }
+                cv_.notify_all();
+                break;
+            }
     }
     ~StagedSource() { stop(); }
     // staged address of chunk c (blocks until it is there); nullptr if a helper thread failed
@@ -2035,7 +2062,10 @@ int hades252_merkle_root_multi(const uint64_t *leaves, size_t n_leaves, int arit
     std::vector<int> rcs(n_workers, HADES252_OK), hip_errs(n_workers, 0);
     std::vector<std::thread> threads;
     for (int g = 0; g < n_workers; g++) {
-        threads.emplace_back([&, g]() {
+        rcs[g] = HADES252_ERR_HIP;                                       // stands if the thread cannot be started
+        hip_errs[g] = (int)hipErrorOutOfMemory;
+        spawn(threads, [&, g]() {
+            rcs[g] = HADES252_OK;
             hipError_t err = F(F_WORKER, hipSetDevice(virt ? g % avail : g));
             if (err != hipSuccess) {
                 rcs[g] = HADES252_ERR_HIP;

@@ -162,7 +162,8 @@ size_t hades252_pool_bytes(void);
  * success; a failing sponge call may already have delivered the digests of its first chunks.
  * Test hook: hades252_fault_inject("<site>:<nth>") makes the nth (1-based) HIP call of that class made by the
  * library from now on fail as if the runtime had refused it; sites: malloc, hostmalloc, hostregister, memcpy,
- * streamcreate, eventcreate, sync, worker (the device selection of one worker thread of the _multi entry points).
+ * streamcreate, eventcreate, sync, worker (the device selection of one worker thread of the _multi entry points),
+ * thread (the start of a helper thread: staging copies, _multi workers; reported as hipErrorOutOfMemory).
  * NULL or "" disarms.  The environment variable HADES252_FAIL_AT holds the same spec for processes that cannot call
  * the hook (read once, at the first library call).  Disarmed cost: one relaxed load per wrapped call. */
 int hades252_fault_inject(const char *spec);

@@ -364,6 +364,51 @@ def test_multi_worker_failure_is_reported_and_survivable(torch_cuda, H, hades_li
     assert (H.merkle_root_multi(lv, 4, TAG4, 1, n_workers=4, virtual=True) == gold).all()
 
 
+def test_helper_thread_that_cannot_start_is_an_error_not_a_crash(torch_cuda, H, hades_lib, oracle):
+    """The system refuses a helper thread (hook site `thread`): staging copies of a big pageable batch, the staged upload of
+    a Merkle call, one worker of the _multi entry points, one slice of the canonical-bytes check.  A return code (or, for
+    the check, the slice done on the calling thread), whole states, no hang, and the next call is right."""
+    lib = hades_lib
+    n = 300000
+    inp = oracle.gen_b(4242, 5 * n)
+    exp = oracle.perm_batch(inp)
+    for nth in (1, 2, 6):
+        buf = inp.copy()
+        H.fault_inject("thread:%d" % nth)
+        rc = lib.hades252_perm_batch(buf.ctypes.data, n)
+        H.fault_inject(None)
+        assert rc == -2 and lib.hades252_last_hip_error() != 0, nth
+        ok, _ = each_state_is_input_or_output(buf, inp, exp)
+        assert ok, nth
+        assert lib.hades252_perm_batch(buf.ctypes.data, n) in (0,)      # (a half-done buffer permuted again: only the rc counts)
+        again = inp.copy()
+        assert lib.hades252_perm_batch(again.ctypes.data, n) == 0 and (again == exp).all(), nth
+    for nth in (1, 5):                                                   # _multi: the nth worker never starts
+        buf = inp.copy()
+        H.fault_inject("thread:%d" % nth)
+        rc = lib.hades252_perm_batch_multi_ex(buf.ctypes.data, n, 8, 1)
+        H.fault_inject(None)
+        assert rc == -2, nth
+        ok, done = each_state_is_input_or_output(buf, inp, exp)
+        assert ok and done < n, (nth, done)
+    leaves = oracle.gen_b(3, 4 ** 9 + 77)                                # 8 MiB + : staged upload
+    want = oracle.merkle_tree(leaves, 4, TAG4, 1)[-1]
+    for nth in (1, 3):
+        root = np.full(4, 0xABCDEF, dtype=np.uint64)
+        H.fault_inject("thread:%d" % nth)
+        rc = lib.hades252_merkle_root(leaves.ctypes.data, 4 ** 9 + 77, 4, H._tag_arr(TAG4), 1, None, root.ctypes.data)
+        H.fault_inject(None)
+        assert rc == -2 and (root == 0xABCDEF).all(), nth
+        assert (H.merkle_root_host(leaves, 4, TAG4, 1) == want).all()
+    k = 60000                                                            # 300 000 scalars: the check runs on several threads
+    b = to_host(H.to_bytes(to_dev(torch_cuda, inp[: 20 * k]).view(-1, 4))).view(np.uint8).copy()
+    H.fault_inject("thread:2")
+    rc = lib.hades252_perm_batch_bytes(b.ctypes.data, k)
+    H.fault_inject(None)
+    want_b = to_host(H.to_bytes(to_dev(torch_cuda, exp[: 20 * k]).view(-1, 4))).view(np.uint8)
+    assert rc == 0 and (b == want_b).all()
+
+
 def test_fault_hook_argument_checking(hades_lib):
     lib = hades_lib
     assert lib.hades252_fault_inject(b"nosuchsite:1") == -1
