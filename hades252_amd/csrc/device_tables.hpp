@@ -28,12 +28,17 @@ __device__ const uint32_t d_rows_klin[59][kNL][16] = HADES_ROWS_KLIN_INIT;
 __device__ const int32_t d_trace_lin[67][kLinRow] = HADES_FAST_TRACE_LIN_INIT;        // as linear maps (mont_lin)
 // ... + D_r: the partial-round constants of words 0..3 that the shipped schedule defers (hades_fast.hpp item 5)
 __device__ const uint32_t d_trace_d[67][5][8] = HADES_FAST_TRACE_D_INIT;
-// witness kernel: un-scaling factors {u_in,u2,u4,u5,w1,u_post} and additive corrections {d1[5], d2[5]} per round
+// witness kernel (true-form schedule, hades252_amd/_derive.py::witness_schedule): round constants as Rp-form addends minus p
+// (c[r]: five words of nine signed-digit limbs; c[67] = zeros), their images under the linear-layer map (ck[r], words 0..3,
+// partial rounds), and the two linear maps: in-memory limbs -> Rp form, and Y -> Y lam 2^29 (the ONE constant product of
+// the linear layer).  __constant__, not const: see d_wire_from_lin below.
 struct WitnessTables {
-    int32_t u[67][64];
-    uint32_t d[67][10][8];
+    int32_t c[68][48];
+    int32_t ck[67][48];
+    int32_t in_lin[kLinRow];
+    int32_t k_lin[kLinRow];
 };
-__device__ const WitnessTables d_wit = {HADES_WITNESS_U_INIT, HADES_WITNESS_D_INIT};
+__constant__ WitnessTables d_wit = {HADES_WITNESS_C_INIT, HADES_WITNESS_CK_INIT, HADES_WITNESS_IN_LIN, HADES_WITNESS_K_LIN};
 // generic radix-2^29 field ops (hades252_fr_op_dev)
 __device__ const int32_t d_rp_mod_p[16] = HADES_RP_MOD_P29;
 // per-operation kernels on the same path (hades252_amd/_derive.py)

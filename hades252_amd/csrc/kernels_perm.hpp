@@ -74,16 +74,50 @@ __global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__
 // PLONK prover assigns per permutation (src/strategies/gadget.rs:41-133: round-0 key additions, v^2 / v^4 / v^5 of
 // each S-box, and per linear layer the 3-term partial sums r1[j] and the rows r2[j] with the NEXT round's constant
 // appended).  Wire-major output: wires[g] is a batch of n scalars (32 B, in-memory BlsScalar), g in gate order.
-// The rounds are those of k_perm_fast; each value is un-scaled with one constant product, fully reduced and, where
-// the shipped schedule defers constants, corrected by a known offset (hades252_amd/_derive.py::witness_schedule;
-// limb-exact replay: tests/test_fast_model.py::witness_model).  Loops over words rotate the state so that every
-// piece of code exists once (I-cache).
+//
+// TRUE-FORM schedule (round 4; hades252_amd/_derive.py::witness_schedule, limb-exact replay
+// tests/test_fast_model.py::witness_model): 972 values leave per permutation, so what a value costs on its way OUT
+// decides the kernel, not the 400-odd products of the permutation itself.  The throughput kernel's running scale would
+// make every gate output pay a 153 multiply-add constant product (round 2-3: 481 k VALU instructions per permutation,
+// issue-bound at 2.3 TB/s of stores).  Here every held value is x * Rp exactly:
+//   * Montgomery products (the S-boxes) are closed in that form, so v^2, v^4, v^5 are gate outputs as they stand;
+//   * the linear layer M = lam C is ONE constant product per word (U = Y lam 2^29, a linear map with the same table every
+//     round) + the small-integer sums over C + the one-limb Montgomery step, which divides the 2^29 out again: rows in
+//     true form, r1 (three columns) and r2 (five) alike;
+//   * a gate output is finalize32 of the held value: the exact division by 32 (Rp / 2^256) with nine multiply-adds and
+//     one conditional subtraction.
+// Round constants enter as Rp-form addends minus p (range discipline of finalize32).  Loops over words rotate the state so
+// that every piece of code exists once (I-cache).
 __device__ __forceinline__ void store_wire(uint8_t *wires, size_t n, int wire, size_t rec, bool live, const Fr &v) {
     if (live) {
         uint4 *q = reinterpret_cast<uint4 *>(wires + ((size_t)wire * n + rec) * 32);
         q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
         q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
     }
+}
+
+// (sum_{k < NCOL} c[k] U_k - m p) / 2^29, normalised: NCOL columns of one row of small_mds (lazy limbs allowed)
+template <int NCOL>
+__device__ __forceinline__ F29 mds_row_cols(const int32_t *crow, const F29 (&u)[5]) {
+    int32_t c[NCOL];
+#pragma unroll
+    for (int k = 0; k < NCOL; k++) c[k] = crow[k];
+    F29 y;
+    int64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < NCOL; k++) mac(acc, u[k].l[0], c[k]);
+    const int32_t m = (int32_t)((uint32_t)acc & kMask29);
+    acc >>= kLB;
+#pragma unroll
+    for (int i = 1; i < kNL; i++) {
+#pragma unroll
+        for (int k = 0; k < NCOL; k++) mac(acc, u[k].l[i], c[k]);
+        mac(acc, m, NEGP29[i]);
+        y.l[i - 1] = (int32_t)((uint32_t)acc & kMask29);
+        acc >>= kLB;
+    }
+    y.l[kNL - 1] = (int32_t)acc;
+    return y;
 }
 
 __global__ void __launch_bounds__(kBlock, 3) k_perm_witness(const uint8_t *__restrict__ states,
@@ -93,92 +127,105 @@ __global__ void __launch_bounds__(kBlock, 3) k_perm_witness(const uint8_t *__res
     const size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
     const size_t rec = rec0 + (threadIdx.x & (kWave - 1));
     const bool live = rec < n;
-    F29 st[5];
+    F29 y[5];                                           // the state WITHOUT the coming round's constants, normalised
     {
         Fr in[5];
         wave_load_records<5>(states, rec0, n, slab, in);
 #pragma unroll
-        for (int w = 0; w < 5; w++) st[w] = to_f29(in[w]);
+        for (int w = 0; w < 5; w++) y[w] = to_f29(in[w]);
+#pragma unroll 1
+        for (int i = 0; i < 5; i++) {                   // in-memory limbs (x 2^256) -> x Rp
+            int off = 0;                                // an offset the compiler cannot see through, per iteration: the 81
+            asm volatile("" : "+s"(off));               // multipliers are NOT to be hoisted out of the loop (as 64-bit values,
+            y[4] = mont_lin(y[4], d_wit.in_lin + off);  // spilling SGPRs and widening every product)
+            rotate_right(y);
+#pragma unroll
+            for (int w = 0; w < 5; w++)
+#pragma unroll
+                for (int k = 0; k < kNL; k++) limb_fence(y[w].l[k]);
+        }
     }
     int wire = 0;
 #pragma unroll 1
     for (int r = 0; r < 67; r++) {
-        const int32_t *rc = d_fast.round[r];
-        const int32_t *u = d_wit.u[r];
+        const int32_t *c = d_wit.c[r], *ck = d_wit.ck[r];
         const bool full = r < 4 || r >= 63;
-        if (full) {
-#pragma unroll
-            for (int w = 0; w < 4; w++) add_lazy(st[w], rc + w * kNL);
-        }
-        add_lazy(st[4], rc + 4 * kNL);
         if (r == 0) {
 #pragma unroll 1
-            for (int i = 0; i < 5; i++) {               // state after the first round key: word 4 - i sits at st[4]
-                store_wire(wires, n, wire + 4 - i, rec, live, finalize(mont_mul_const(st[4], u)));
-                rotate_right(st);
+            for (int i = 0; i < 5; i++) {               // state after the first round key: word 4 - i sits at y[4]
+                F29 s = y[4];
+                add_lazy(s, c + (4 - i) * kNL);
+                store_wire(wires, n, wire + 4 - i, rec, live, finalize32(s));
+                rotate_right(y);
             }
             wire += 5;
         }
-        // S-boxes: v^2, v^4, v^5 (partial round: word 4 only, then the K_r product that re-scales it)
+        // S-boxes: every word (full round: word 4 - i rotates through y[4]) or word 4 alone
         const int cnt = full ? 5 : 1;
 #pragma unroll 1
         for (int i = 0; i < cnt; i++) {
-            const int w = full ? 4 - i : 0;             // gate order: word 0 first (a partial round has one S-box)
-            const F29 v2 = mont_sqr(st[4]);
-            store_wire(wires, n, wire + 3 * w, rec, live, finalize(mont_mul_const(v2, u + kNL)));
-            const F29 v4 = mont_sqr(v2);
-            store_wire(wires, n, wire + 3 * w + 1, rec, live, finalize(mont_mul_const(v4, u + 2 * kNL)));
-            F29 v5 = mont_mul(v4, st[4]);
-            if (!full) v5 = mont_mul_const(v5, rc + 5 * kNL);
-            store_wire(wires, n, wire + 3 * w + 2, rec, live, finalize(mont_mul_const(v5, u + 3 * kNL)));
-            st[4] = v5;
-            if (full) rotate_right(st);
+            const int w = 4 - i;
+            const int g = wire + (full ? 3 * w : 0);        // gate order: word 0 first (a partial round has one S-box)
+            F29 z = y[4];
+            add_lazy(z, c + w * kNL);
 #pragma unroll
-            for (int k = 0; k < kNL; k++) limb_fence(st[4].l[k]);
+            for (int k = 0; k < kNL; k++) limb_fence(z.l[k]);
+            F29 v2 = mont_sqr(z);
+            store_wire(wires, n, g, rec, live, finalize32(v2));
+            // (a store is a branch on `live`; instruction selection works block by block, and a limb whose 64-bit
+            // extension was computed in an earlier block is multiplied as a 64-bit value -- three instructions per
+            // product instead of one.  The fences make the operands 32-bit values of THIS block.)
+#pragma unroll
+            for (int k = 0; k < kNL; k++) limb_fence(v2.l[k]);
+            F29 v4 = mont_sqr(v2);
+            store_wire(wires, n, g + 1, rec, live, finalize32(v4));
+#pragma unroll
+            for (int k = 0; k < kNL; k++) {
+                limb_fence(v4.l[k]);
+                limb_fence(z.l[k]);
+            }
+            z = mont_mul(v4, z);
+            store_wire(wires, n, g + 2, rec, live, finalize32(z));
+            y[4] = z;
+            if (full) rotate_right(y);
+#pragma unroll
+            for (int w2 = 0; w2 < 5; w2++)
+#pragma unroll
+                for (int k = 0; k < kNL; k++) limb_fence(y[w2].l[k]);
         }
         wire += 3 * cnt;
-        // r1[j] = M[j][0] z0 + M[j][1] z1 + M[j][2] z2: three columns of the small-integer layer, one-limb step
+        // the constant product of the linear layer, U_w = Y_w lam 2^29; in a partial round words 0..3 carry their round
+        // constant through the map as an addend
+#pragma unroll
+        for (int w = 0; w < 5; w++) {
+            int off = 0;                                // an offset the compiler cannot see through, per use: the 81
+            asm volatile("" : "+s"(off));               // multipliers are NOT to be hoisted out of the round loop or shared
+            y[w] = mont_lin(y[w], d_wit.k_lin + off);   // between the five maps (as 64-bit values: SGPR spills, widened products)
+            if (w < 4 && !full) add_lazy(y[w], ck + w * kNL);
+        }
+        // the linear layer over U = y.  r1[j]: columns 0..2 of row j, a gate output only; then the rows themselves in
+        // place (small_mds, limb-major: no second copy of the state); r2[j] = row j + the next round's constant
 #pragma unroll 1
         for (int j = 0; j < 5; j++) {
-            const int32_t c0 = d_coop.mds[j][0], c1 = d_coop.mds[j][1], c2 = d_coop.mds[j][2];
-            F29 y;
-            int64_t acc = 0;
-            mac(acc, st[0].l[0], c0);
-            mac(acc, st[1].l[0], c1);
-            mac(acc, st[2].l[0], c2);
-            const int32_t m = (int32_t)((uint32_t)acc & kMask29);
-            acc >>= kLB;
 #pragma unroll
-            for (int k = 1; k < kNL; k++) {
-                mac(acc, st[0].l[k], c0);
-                mac(acc, st[1].l[k], c1);
-                mac(acc, st[2].l[k], c2);
-                mac(acc, m, NEGP29[k]);
-                y.l[k - 1] = (int32_t)((uint32_t)acc & kMask29);
-                acc >>= kLB;
-            }
-            y.l[kNL - 1] = (int32_t)acc;
-            Fr v = finalize(mont_mul_const(y, u + 4 * kNL));
-            if (!full) v = fr_add(v, load_const(d_wit.d[r], j));
-            store_wire(wires, n, wire + 2 * j, rec, live, v);
-        }
-        small_mds(st);
-        // r2[j] = row j of the linear layer + the next round's constant
-#pragma unroll 1
-        for (int i = 0; i < 5; i++) {
-            const int j = 4 - i;
-            Fr v = finalize(mont_mul_const(st[4], u + 5 * kNL));
-            v = fr_add(v, load_const(d_wit.d[r], 5 + j));
-            store_wire(wires, n, wire + 2 * j + 1, rec, live, v);
-            rotate_right(st);
+            for (int w = 0; w < 3; w++)
 #pragma unroll
-            for (int k = 0; k < kNL; k++) limb_fence(st[4].l[k]);
+                for (int k = 0; k < kNL; k++) limb_fence(y[w].l[k]);
+            store_wire(wires, n, wire + 2 * j, rec, live, finalize32(mds_row_cols<3>(d_coop.mds[j], y)));
         }
-        wire += 10;
+        small_mds(y);
+        const int32_t *cn = d_wit.c[r + 1];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            F29 s = y[j];
+            add_lazy(s, cn + j * kNL);
+            store_wire(wires, n, wire + 2 * j + 1, rec, live, finalize32(s));
+        }
 #pragma unroll
         for (int w = 0; w < 5; w++)
 #pragma unroll
-            for (int k = 0; k < kNL; k++) limb_fence(st[w].l[k]);
+            for (int k = 0; k < kNL; k++) limb_fence(y[w].l[k]);
+        wire += 10;
     }
 }
 

@@ -9,6 +9,7 @@ silently undo either.  This test compiles the device code to assembly for gfx950
                    waves/SIMD by registers; the LDS slab admits 3), the linear map's multipliers fetched a column at a
                    time (no dword-by-dword scalar loads)
   every hot kernel 0 scratch (sponge, Merkle, trace, cooperative, per-lane level) -- round 1's sponge spilled
+  k_perm_witness   one multiply-add per limb product in its rolled loops too (no hoisted tables, no widened operands)
 """
 import os
 import re
@@ -90,6 +91,25 @@ def test_wire_kernels_keep_their_occupancy(device_asm):
     for name in find(res, "k_wire"):
         want = 6 if "ILi1E" in name else 8
         assert res[name]["Occupancy"] >= want, (name, res[name])
+
+
+def test_witness_kernel_products_stay_single_multiply_adds(device_asm):
+    """k_perm_witness (true-form schedule) is rolled loops around stores that branch on `live`.  Two things went wrong while
+    it was written and would again silently: (i) a loop-invariant linear-map table is hoisted out of the loop as 81 64-bit
+    values (SGPR spills, every product widened), (ii) a limb whose sign extension was computed in an earlier basic block is
+    multiplied as a 64-bit value (v_mul_lo_u32 pairs around a v_mad_u64_u32).  One multiply-add per limb product:
+    6 linear maps (97: the input's, rolled, + five unrolled) + S-box (117 + 117 + 153) + r1 row (35) + rows (265) + 10
+    finalize32 (9) = 1359."""
+    bodies, res = device_asm
+    (name,) = find(bodies, "k_perm_witness")
+    body = bodies[name]
+    mads = len(re.findall(r"\bv_mad_[iu]64_[iu]32\b", body))
+    widened = len(re.findall(r"\bv_mul_lo_u32\b", body))
+    assert abs(mads - 1359) <= 0.02 * 1359, mads
+    assert widened <= 6, "%d v_mul_lo_u32: limb products are being widened to 64 x 32 bits" % widened
+    assert "flat_load" not in body and "scratch_" not in body
+    r = res[name]
+    assert r["SGPRs Spill"] == 0 and r["VGPRs"] <= 112, r
 
 
 def test_perm_lanes_instruction_mix(device_asm):

@@ -318,70 +318,121 @@ def test_coop_model_matches_spec_oracle():
         assert got == [S.to_mont(v) for v in S.perm(vals)]
 
 
+def finalize32_model(x):
+    """finalize32 of hades_fast.hpp: x / 32 mod p, fully reduced, for an Rp-form value x in (-2p - 2^232, p / 8) with lazy
+    limbs: m = (-x mod 32) + 32 makes x + m p a multiple of 32 in (30 p, 64 p); one conditional subtraction."""
+    v = val(x)
+    assert -2 * P - (1 << 232) < v < (P >> 3), "finalize32: input outside its window"
+    assert all(abs(l) < I31 - (1 << LB) for l in x)
+    m = ((-x[0]) & 31) + 32
+    out, carry = [], 0
+    for k in range(NL):
+        t = m * P29[k] + x[k] + carry                # one multiply-add on a 32-bit carry chain
+        assert abs(x[k] + carry) < I31 and abs(t) < (1 << 40)
+        out.append(t & MASK if k < NL - 1 else t)
+        carry = t >> LB
+    assert 0 <= out[NL - 1] < (1 << LB), "the sum is below 64 p < 2^261"
+    t = val(out)
+    assert t == v + m * P and t % 32 == 0
+    t >>= 5                                          # the packing reads bits [5, 261)
+    assert 0 < t < 2 * P and t < (1 << 256)
+    return t - P if t >= P else t
+
+
+def mds_row_cols(u, j, ncol):
+    """mds_row_cols<NCOL> of kernels_perm.hpp: (sum_{k < ncol} C[j][k] U_k - m p) / 2^29, normalised; lazy limbs allowed."""
+    acc = sum(u[c][0] * D.MDS_SMALL[j][c] for c in range(ncol))
+    check_acc(acc)
+    m = acc & MASK
+    acc >>= LB
+    out = [0] * NL
+    for kk in range(1, NL):
+        acc += sum(u[c][kk] * D.MDS_SMALL[j][c] for c in range(ncol)) - m * P29[kk]
+        assert abs(acc) < (1 << 60)
+        out[kk - 1] = acc & MASK
+        acc >>= LB
+    assert -I31 <= acc < I31
+    out[NL - 1] = acc
+    assert normalised(out)
+    return out
+
+
+def add_lazy(x, c):
+    r = [a + b for a, b in zip(x, c)]
+    assert all(-LAZY < l < LAZY for l in r)
+    return r
+
+
 def witness_model(mont_vals):
-    """Limb-exact replay of k_perm_witness: the rounds of k_perm_fast with every gate output of the reference's
-    GadgetStrategy un-scaled on the way (hades252_amd/_derive.py::witness_schedule)."""
-    sch, ws = D.fast_schedule(), D.witness_schedule()
-    st = [D.to_limbs29(v) for v in mont_vals]
+    """Limb-exact replay of k_perm_witness (kernels_perm.hpp): the TRUE-FORM schedule of
+    hades252_amd/_derive.py::witness_schedule -- every held value is x * Rp, Montgomery products are closed in that form,
+    the linear layer is one constant linear map per word (U = Y lam 2^29) + the small-integer rows + the one-limb step,
+    and every gate output of the reference's GadgetStrategy leaves through finalize32 (the exact division by 32)."""
+    ws = D.witness_schedule()
+    c = [[D.to_balanced29_signed(v) for v in row] for row in ws["c"]]
+    ck = [[D.to_balanced29(v) for v in row] for row in ws["ck"]]
+    y = [mont_lin(D.to_limbs29(v), ws["f_in"]) for v in mont_vals]          # x Rp, normalised, no constants yet
     wires = []
-
-    def emit(x, factor, add=0):
-        wires.append((finalize_model(x, factor) + add * S.R) % P)
-
     for r in range(D.ROUNDS):
         full = D.is_full_round(r)
-        w = ws[r]
-        a, k = (sch["full"][r], None) if full else sch["part"][r]
-        for i in (range(5) if full else (4,)):
-            st[i] = [x + y for x, y in zip(st[i], D.to_balanced29(a[i]))]
         if r == 0:
-            for i in range(5):
-                emit(st[i], w["u_in"])
-        for i in (range(5) if full else (4,)):
-            v2 = mont_fips(st[i], st[i], True)
-            emit(v2, w["u2"])
-            v4 = mont_fips(v2, v2, True)
-            emit(v4, w["u4"])
-            v5 = mont_fips(v4, st[i])
-            if not full:
-                v5 = mont_fips(v5, D.to_limbs29(k))
-            emit(v5, w["u5"])
-            st[i] = v5
-        # three-term partial sums, one-limb Montgomery step, normalised (same pass as small_mds with 3 columns)
-        y1 = []
+            wires += [finalize32_model(add_lazy(y[w], c[0][w])) for w in range(5)]
+        u = [None] * 5
+        for w in range(5):
+            if full or w == 4:
+                z = add_lazy(y[w], c[r][w])
+                v2 = mont_fips(z, z, True)
+                v4 = mont_fips(v2, v2, True)
+                v5 = mont_fips(v4, z)
+                wires += [finalize32_model(v2), finalize32_model(v4), finalize32_model(v5)]
+                u[w] = mont_lin(v5, ws["f_k"])
+            else:
+                u[w] = add_lazy(mont_lin(y[w], ws["f_k"]), ck[r][w])        # the round constant, seen through the map
         for j in range(5):
-            acc = sum(st[c][0] * D.MDS_SMALL[j][c] for c in range(3))
-            m = acc & MASK
-            acc >>= LB
-            out = [0] * NL
-            for kk in range(1, NL):
-                acc += sum(st[c][kk] * D.MDS_SMALL[j][c] for c in range(3)) - m * P29[kk]
-                assert abs(acc) < (1 << 60)
-                out[kk - 1] = acc & MASK
-                acc >>= LB
-            assert -I31 <= acc < I31
-            out[NL - 1] = acc
-            assert normalised(out)
-            y1.append(out)
-        st = small_mds(st)
+            wires.append(finalize32_model(mds_row_cols(u, j, 3)))
+            wires.append(None)                                              # r2[j]: after the rows
+        y = small_mds(u)
+        assert y == [mds_row_cols(u, j, 5) for j in range(5)]
         for j in range(5):
-            emit(y1[j], w["w1"], w["d1"][j])
-            emit(st[j], w["u_post"], w["d2"][j])
+            wires[len(wires) - 10 + 2 * j + 1] = finalize32_model(add_lazy(y[j], c[r + 1][j]))
+    # gate order: in a full round the S-box gates come word 0 first
     return wires
 
 
 def test_witness_model_matches_gadget_schedule():
     """Every one of the 972 gate outputs of the reference's GadgetStrategy (oracle: hades_spec.perm_gadget,
-    src/strategies/gadget.rs:41-133) from the scale-tracked rounds."""
+    src/strategies/gadget.rs:41-133) from the true-form rounds; all machine-word bounds and finalize32's window are asserted
+    on the way."""
     rng = random.Random(53)
     assert D.WITNESS_WIRES == 972
-    for vals in ([5000] * 5, [P - 1, 0, 1, P - 2, 2], [rng.randrange(P) for _ in range(5)]):
+    cases = [[5000] * 5, [P - 1, 0, 1, P - 2, 2], [0] * 5, [P - 1] * 5]
+    cases += [[rng.choice(EDGE) for _ in range(5)] for _ in range(3)]
+    cases += [[rng.randrange(P) for _ in range(5)] for _ in range(3)]
+    for vals in cases:
         spec = []
         S.perm_gadget(vals, spec)
         got = witness_model([S.to_mont(v) for v in vals])
         assert len(got) == len(spec) == 972
         bad = [i for i in range(972) if got[i] != S.to_mont(spec[i])]
         assert not bad, bad[:10]
+
+
+def test_finalize32_window_adversarial():
+    """finalize32 on the extremes of what the witness kernel hands it: products (mont_fips of lazy operands: (-p - 2^253,
+    2^253)), rows with and without an appended constant ((-2p - eps, eps)), and the window's own edges."""
+    rng = random.Random(59)
+    top = (P >> 3) - 1
+    for v in [0, 1, -1, 31, -31, 32, top, top - 1, -2 * P - (1 << 232) + 1, -2 * P, -P, -P + 1, -P - 1, P >> 4] + \
+             [rng.randrange(-2 * P, P >> 3) for _ in range(300)]:
+        got = finalize32_model(D.to_balanced29_signed(v))
+        assert got == v * pow(32, -1, P) % P
+        if 0 <= v < (P >> 3):
+            assert finalize32_model(D.to_limbs29(v)) == got                 # plain limbs, same value
+    # lazy limbs at the bound: a normalised value + a balanced addend
+    for _ in range(50):
+        a, b = rng.randrange(P >> 4), rng.randrange(P)
+        x = [p + q for p, q in zip(D.to_limbs29(a), D.to_balanced29_signed(b - P))]
+        assert finalize32_model(x) == (a + b - P) * pow(32, -1, P) % P
 
 
 def test_per_op_models_match_spec_oracle():
