@@ -242,6 +242,48 @@ def test_witness_rows_equal_trace_plus_next_round_key(torch_cuda, H, oracle):
     assert base == 972
 
 
+def test_witness_every_gate_identity_at_scale(torch_cuda, H, oracle):
+    """All 972 wires of 4 096 states against the GATES themselves (src/strategies/gadget.rs:59-69, :102-129), evaluated by
+    the device field ops on the kernel's own outputs: every S-box triple (v2 = v v, v4 = v2 v2, v5 = v4 v with v the wire
+    that feeds it), every r1 = M[j][0] z0 + M[j][1] z1 + M[j][2] z2 and r2 = r1 + M[j][3] z3 + M[j][4] z4 + c.  Together
+    with the first five wires (input + round key) this pins every wire to the input by induction."""
+    torch = torch_cuda
+    n = 1 << 12
+    st = H.gen_b(5 * n, "cuda", first_elem=99)
+    w = H.perm_witness(st)
+    mul = lambda a, b: H.fr_op(H.FR_MUL, a.contiguous(), b.contiguous())
+    add = lambda a, b: H.fr_op(H.FR_ADD, a.contiguous(), b.contiguous())
+    const = lambda v: scalars_dev(torch, [S.to_mont(v)]).expand(n, 4).contiguous()   # v: canonical integer
+    mds = [[const(v) for v in row] for row in S.mds_matrix()]
+    ark = S.round_constants()
+    state = []
+    for j in range(5):                                                          # wires 0..4: input + first round key
+        state.append(w[j])
+        assert torch.equal(w[j], add(st.view(n, 5, 4)[:, j, :], const(ark[j]))), j
+    g = 5
+    for r in range(67):
+        full = r < 4 or r >= 63
+        z = list(state)
+        for word in (range(5) if full else (4,)):
+            v = state[word]
+            assert torch.equal(w[g], mul(v, v)) and torch.equal(w[g + 1], mul(w[g], w[g])), (r, word)
+            assert torch.equal(w[g + 2], mul(w[g + 1], v)), (r, word)
+            z[word] = w[g + 2]
+            g += 3
+        nxt = []
+        for j in range(5):
+            r1 = add(add(mul(mds[j][0], z[0]), mul(mds[j][1], z[1])), mul(mds[j][2], z[2]))
+            assert torch.equal(w[g], r1), (r, j)
+            r2 = add(add(mul(mds[j][3], z[3]), mul(mds[j][4], z[4])), w[g])
+            if r < 66:
+                r2 = add(r2, const(ark[5 * (r + 1) + j]))
+            assert torch.equal(w[g + 1], r2), (r, j)
+            nxt.append(w[g + 1])
+            g += 2
+        state = nxt
+    assert g == 972
+
+
 # ---------------------------------------------------------------------------------------------
 # variable-length sponge
 # ---------------------------------------------------------------------------------------------
