@@ -265,6 +265,35 @@ def wire_format_record(H, torch, device, log_n=26):
     return rec
 
 
+def gadget_witness_record(H, torch, device, log_n=20):
+    """every gate output GadgetStrategy assigns (972 per permutation,
+    src/strategies/gadget.rs:41-133) for 2^log_n states -- 31 104 bytes written per state, so the kernel is priced against
+    the HBM roofline.  HIP events, median of 5; the last round's rows must equal the permutation of the same states."""
+    n = 1 << log_n
+    st = H.gen_b(5 * n, device)
+    wires = torch.empty((H.witness_wires(), n, 4), dtype=torch.int64, device=device)
+    H.perm_witness(st, out=wires)
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        H.perm_witness(st, out=wires)
+        b.record()
+        torch.cuda.synchronize()
+        ms.append(a.elapsed_time(b))
+    med = sorted(ms)[2]
+    nw = wires.shape[0]
+    last = torch.stack([wires[nw - 10 + 2 * j + 1] for j in range(5)], dim=1).reshape(-1)
+    out = st.clone()
+    H.ScalarStrategy().perm(out)
+    ach = (160.0 + 32.0 * nw) * n / (med * 1e-3) / 1e9
+    return {"workload": "2^%d states, %d wires of 32 B each per state" % (log_n, nw), "ms": med,
+            "perms_per_s": n / (med * 1e-3), "last_rows_equal_perm": bool(torch.equal(last, out.reshape(-1))),
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_state": 160 + 32 * nw}}
+
+
 def sponge_chain_record(H, torch, device, blocks=1000):
     """The reference's consumer (dusk-poseidon's sponge, README.md:9) at its hardest shape for a GPU: ONE message, a chain
     of `blocks` dependent permutations.  Whole call (HIP events), microseconds per block; the CPU port's time for one
@@ -497,6 +526,8 @@ def main():
             sec["single_perm"] = single_perm_record(H, torch, device)
             sec["sponge_chain"] = sponge_chain_record(H, torch, device)
             sec["wire_format"] = wire_format_record(H, torch, device)
+            torch.cuda.empty_cache()
+            sec["gadget_witness"] = gadget_witness_record(H, torch, device)
             torch.cuda.empty_cache()
             sec["host_path"] = host_path_record(22)
         except Exception as e:                       # secondary records never take the headline down

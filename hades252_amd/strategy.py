@@ -367,6 +367,11 @@ def perm_trace(states_t, kernel: int = _lib.KERNEL_DEFAULT, out=None):
     return trace
 
 
+def witness_wires() -> int:
+    """Gate outputs per permutation (972): the first dimension of what ``perm_witness`` returns."""
+    return int(_lib.lib().hades252_witness_wires())
+
+
 def perm_witness(states_t, out=None):
     """Every gate output of the reference's GadgetStrategy (src/strategies/gadget.rs:41-133) for every state:
     [972, n, 4] int64, wire-major in gate order (include/hades252.h).  The input is left untouched."""
