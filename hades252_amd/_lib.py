@@ -65,6 +65,7 @@ SIGNATURES = {
     "hades252_perm_trace_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "hades252_perm_trace_dev_ex": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
     "hades252_witness_wires": (c_int, []),
+    "hades252_warm_up": (c_int, [c_size_t]),
     "hades252_perm_witness_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "hades252_add_round_key_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
     "hades252_add_round_key_at_dev": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),

@@ -908,6 +908,25 @@ int hades252_perm_batch(uint64_t *states, size_t n_perms) {
     return perm_batch_host_on_current_device(states, n_perms, false);
 }
 
+// Pays the one-time costs now instead of inside the first real call: the code object is loaded by a one-state permutation
+// on an internal buffer (~35 ms in a fresh process), and -- for a hint above 256 states -- the pipe such a batch would
+// take (streams, events, chunk buffers; the page-locked staging buffers too when the hint is big enough for the
+// staging-thread path) is created and put into the pool.
+int hades252_warm_up(size_t n_perms_hint) {
+    int rc = check_device();
+    if (rc != HADES252_OK) return rc;
+    uint64_t one[20] = {0};
+    rc = perm_batch_host_on_current_device(one, 1, false);
+    if (rc != HADES252_OK || n_perms_hint <= kPinnedStates) return rc;
+    const size_t chunk = n_perms_hint < host_chunk_states(n_perms_hint) ? n_perms_hint : host_chunk_states(n_perms_hint);
+    HostPipe pipe;
+    rc = acquire_pipe(chunk * 160, pipe);
+    if (rc != HADES252_OK) return rc;
+    if (host_pin_enabled() && n_perms_hint > 2 * kStageChunkStates) rc = pipe_ensure_stage(pipe);
+    release_pipe(pipe, rc != HADES252_OK);
+    return rc;
+}
+
 // input validation only (BlsScalar::from_bytes fails for values >= p before anything is computed)
 static bool all_canonical(const uint8_t *bytes, size_t n_scalars) {
     static const uint64_t kP[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull,

@@ -224,6 +224,11 @@ def kernel_name(kernel: int = _lib.KERNEL_DEFAULT, n_perms: int = 0) -> str:
     return name.decode()
 
 
+def warm_up(n_perms_hint: int = 0) -> None:
+    """``hades252_warm_up``: load the code object and pre-create the pipe a host batch of ``n_perms_hint`` states would take."""
+    check(_lib.lib().hades252_warm_up(int(n_perms_hint)), "warm_up")
+
+
 def trim() -> None:
     """``hades252_trim``: give back everything the pool of pipes caches (device memory, streams, staging buffers)."""
     check(_lib.lib().hades252_trim(), "trim")

@@ -142,6 +142,13 @@ int hades252_stream_create(void **stream);
 int hades252_stream_destroy(void *stream);
 int hades252_stream_sync(void *stream);
 
+/* Optional.  Pays the one-time costs of the host-pointer path now instead of inside the first real call: loads the code
+ * object (a one-state permutation on an internal buffer: ~35 ms in a fresh process) and, for n_perms_hint > 256, creates
+ * the pipe a batch of that size would take -- streams, events, device chunk buffers, and the page-locked staging buffers
+ * when the hint is large enough for the staging-thread path of ordinary memory -- and leaves it in the pool.  Current
+ * device; a caller of the _multi entry points calls it once per device. */
+int hades252_warm_up(size_t n_perms_hint);
+
 /* ---- what the library caches, and how to give it back ---------------------------------------------------------
  * The host-pointer entry points reuse "pipes" (three streams, events, chunk buffers and a scratch arena in device memory,
  * a small page-locked staging buffer) so that a call pays no allocation.  The pool is bounded: per device it keeps at most

@@ -181,6 +181,8 @@ inline void sponge_hash(const BlsScalar *msgs, std::size_t n_msgs, std::size_t m
 // What the library caches (pipes: streams, chunk buffers, staging memory) and which kernel a batch size gets.
 inline void trim() { check(hades252_trim(), "trim"); }
 inline std::size_t pool_bytes() { return hades252_pool_bytes(); }
+/// Pay the one-time costs (code object, pipe for a host batch of `n_perms_hint` states) before the first real call.
+inline void warm_up(std::size_t n_perms_hint = 0) { check(hades252_warm_up(n_perms_hint), "warm_up"); }
 inline int kernel_for(std::size_t n_perms) { return hades252_kernel_for(n_perms); }
 inline const char *kernel_name(int kernel, std::size_t n_perms) { return hades252_kernel_name(kernel, n_perms); }
 

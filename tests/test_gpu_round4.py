@@ -409,6 +409,33 @@ def test_helper_thread_that_cannot_start_is_an_error_not_a_crash(torch_cuda, H, 
     assert rc == 0 and (b == want_b).all()
 
 
+def test_warm_up_prepays_the_first_call(torch_cuda, H, hades_lib, oracle):
+    """hades252_warm_up(hint): the pool holds the pipe a batch of that size takes (device chunk buffers; staging buffers
+    for the pageable path), the next call of that size allocates nothing more, results are right; a failing allocation
+    during warm-up is a return code and leaves nothing behind."""
+    lib = hades_lib
+    H.trim()
+    assert H.pool_bytes() == 0
+    H.warm_up(0)
+    assert H.pool_bytes() == 0                                    # a small call's pipe has no device chunk buffers
+    n = 300000
+    H.warm_up(n)
+    held = H.pool_bytes()
+    assert held > 0
+    inp = oracle.gen_b(31337, 5 * n)
+    buf = inp.copy()
+    assert lib.hades252_perm_batch(buf.ctypes.data, n) == 0
+    assert (buf == oracle.perm_batch(inp)).all()
+    assert H.pool_bytes() == held                                 # the warmed pipe served the call
+    H.trim()
+    H.fault_inject("malloc:1")
+    rc = lib.hades252_warm_up(n)
+    H.fault_inject(None)
+    assert rc == -2 and H.pool_bytes() == 0
+    H.warm_up(n)
+    assert H.pool_bytes() == held
+
+
 def test_fault_hook_argument_checking(hades_lib):
     lib = hades_lib
     assert lib.hades252_fault_inject(b"nosuchsite:1") == -1
