@@ -386,37 +386,6 @@ __device__ __forceinline__ Fr finalize1(const F29 &x) {
     return fr_cond_sub_p(from_f29(y));
 }
 
-// x / 32 mod p, fully reduced, for x in (-2p - 2^232, p / 8): the step from the Rp form (value * 2^261) every true-form
-// kernel holds to the in-memory BlsScalar (value * 2^256).  Exact division Montgomery-style: p == 1 (mod 32), so with
-// m = (-x mod 32) + 32 the sum x + m p is a multiple of 32; it lies in (30 p, 64 p) and its 32nd part in (0.93 p, 2 p): ONE
-// conditional subtraction.  Nine multiply-adds (m p, limb by limb, on a 32-bit carry chain) and the 9 x 29 -> 8 x 32
-// packing shifted down by five bits -- against a 153 multiply-add constant product + finalize when the held value
-// carries a running scale.  Lazy limbs welcome (|limb| < 2^31 - 2^29).  tests/test_fast_model.py::finalize32_model.
-__device__ __forceinline__ Fr finalize32(const F29 &x) {
-    const int32_t m = ((0 - x.l[0]) & 31) + 32;
-    F29 y;
-    int32_t carry = 0;
-#pragma unroll
-    for (int k = 0; k < kNL; k++) {
-        const int64_t t = (int64_t)m * P29[k] + (int64_t)(x.l[k] + carry);
-        y.l[k] = (int32_t)((uint32_t)t & kMask29);
-        carry = (int32_t)(t >> kLB);
-        if (k == kNL - 1) y.l[k] = (int32_t)t;                   // below 2^29: the sum is below 64 p < 2^261
-    }
-    Fr r;
-#pragma unroll
-    for (int w = 0; w < 8; w++) {                                  // word w = bits [32 w + 5, 32 w + 37) of the sum
-        const int bit = 32 * w + 5, k = bit / kLB, sh = bit - kLB * k;
-        uint64_t acc = (uint64_t)(uint32_t)y.l[k] >> sh;
-        int have = kLB - sh;
-        if (k + 1 < kNL) acc |= (uint64_t)(uint32_t)y.l[k + 1] << have;
-        have += kLB;
-        if (have < 32 && k + 2 < kNL) acc |= (uint64_t)(uint32_t)y.l[k + 2] << have;
-        r.l[w] = (uint32_t)acc;
-    }
-    return fr_cond_sub_p(r);
-}
-
 // in: 5 BlsScalars (Montgomery 2^256 form, fully reduced); out: same format, fully reduced.
 template <int NOUT>
 __device__ __forceinline__ void fast_perm(const FastTables *T, const Fr (&in)[5], Fr (&out)[NOUT], int out_first) {

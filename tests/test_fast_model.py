@@ -319,7 +319,7 @@ def test_coop_model_matches_spec_oracle():
 
 
 def finalize32_model(x):
-    """finalize32 of hades_fast.hpp: x / 32 mod p, fully reduced, for an Rp-form value x in (-2p - 2^232, p / 8) with lazy
+    """finalize32 of kernels_perm.hpp: x / 32 mod p, fully reduced, for an Rp-form value x in (-2p - 2^232, p / 8) with lazy
     limbs: m = (-x mod 32) + 32 makes x + m p a multiple of 32 in (30 p, 64 p); one conditional subtraction."""
     v = val(x)
     assert -2 * P - (1 << 232) < v < (P >> 3), "finalize32: input outside its window"
