@@ -1090,7 +1090,7 @@ int hades252_perm_witness_dev(const void *d_states, void *d_wires, size_t n_perm
     if (d_states == nullptr || d_wires == nullptr || n_perms > kMaxLaunchRecords || misaligned(d_states) ||
         misaligned(d_wires))
         return HADES252_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(k_perm_witness, dim3(blocks_for(n_perms)), dim3(kBlock), lds_for(5), (hipStream_t)stream,
+    hipLaunchKernelGGL(k_perm_witness, dim3(blocks_for(n_perms)), dim3(kBlock), 0, (hipStream_t)stream,
                        (const uint8_t *)d_states, (uint8_t *)d_wires, n_perms);
     HIP_TRY(hipGetLastError());
     return HADES252_OK;

@@ -151,17 +151,17 @@ __device__ __forceinline__ F29 mds_row_cols(const int32_t *crow, const F29 (&u)[
     return y;
 }
 
-__global__ void __launch_bounds__(kBlock, 3) k_perm_witness(const uint8_t *__restrict__ states,
+__global__ void __launch_bounds__(kBlock, 5) k_perm_witness(const uint8_t *__restrict__ states,
                                                             uint8_t *__restrict__ wires, size_t n) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t *slab = wave_slab<5>(lds);
-    const size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
-    const size_t rec = rec0 + (threadIdx.x & (kWave - 1));
+    const size_t rec = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = rec < n;
     F29 y[5];                                           // the state WITHOUT the coming round's constants, normalised
     {
+        // 160 bytes in against 31 104 out: the lanes fetch their own records (no LDS slab, which would cap the kernel at
+        // three waves per SIMD; its 92 VGPRs admit five)
         Fr in[5];
-        wave_load_records<5>(states, rec0, n, slab, in);
+#pragma unroll
+        for (int w = 0; w < 5; w++) in[w] = live ? load_word(states + rec * 160 + w * 32) : zero_word();
 #pragma unroll
         for (int w = 0; w < 5; w++) y[w] = to_f29(in[w]);
 #pragma unroll 1
