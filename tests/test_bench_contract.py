@@ -33,7 +33,7 @@ def test_bench_single_and_two_ranks_agree():
     # outside `value`: BASELINE configs[3] and the host-pointer boundary (native caller, PCIe-inclusive)
     mk, hp = one["secondary"]["merkle_2p24"], one["secondary"]["host_path"]
     assert mk["nodes"] == 5592405 and 0 < mk["tree_ms"] < 100 and mk["roofline"]["algorithmic_bytes_per_node"] == 160
-    assert hp["bit_exact_vs_device_path"] is True and 0 < hp["frac_of_ceiling"] < 1.2 and hp["perms"] == 1 << 22
+    assert hp["bit_exact_vs_device_path"] is True and 0 < hp["frac_of_ceiling"] < 2.0 and hp["perms"] == 1 << 22   # (> 1: a box whose bare copies run below the pipeline)
     sp = one["secondary"]["single_perm"]
     assert 20 < sp["device_us_median"] < 150 and sp["device_us_min"] <= sp["host_call_us_median"] < 400
     assert 20 < one["secondary"]["sponge_chain"]["us_per_block"] < 150

@@ -26,37 +26,45 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 #define HK(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hades252_strerror(r_)); exit(1); } } while (0)
 
-// bare hipMemcpyAsync both ways at once, 20 MiB pieces, page-locked memory; best of several fresh stream pairs
+// bare hipMemcpyAsync both ways at once, page-locked memory; best over fresh stream pairs, piece sizes (10 / 20 / 40 MiB)
+// and BOTH kinds of page-locked allocation (the runtime's default and the portable + mapped kind hades252_host_alloc
+// hands out: on some boxes of the pool device -> host copies into the default kind run at half rate, 27 instead of
+// 57 GB/s, and a "ceiling" measured on it alone came out below what the library's pipeline achieved)
 static double ceiling_seconds(size_t bytes, double *h2d_alone, double *d2h_alone) {
-    uint8_t *h_in, *h_out, *d_in, *d_out;
-    CK(hipHostMalloc((void **)&h_in, bytes, hipHostMallocDefault));
-    CK(hipHostMalloc((void **)&h_out, bytes, hipHostMallocDefault));
+    uint8_t *d_in, *d_out;
     CK(hipMalloc((void **)&d_in, bytes));
     CK(hipMalloc((void **)&d_out, bytes));
-    memset(h_in, 1, bytes);
-    memset(h_out, 1, bytes);
-    const size_t piece = (size_t)20 << 20;
     double best[3] = {1e9, 1e9, 1e9};
-    for (int pair = 0; pair < 4; pair++) {
-        hipStream_t s1, s2;
-        CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
-        CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-        for (int rep = 0; rep < 3; rep++)
-            for (int mode = 0; mode < 3; mode++) {
-                CK(hipDeviceSynchronize());
-                double t0 = now();
-                for (size_t off = 0; off < bytes; off += piece) {
-                    size_t n = std::min(piece, bytes - off);
-                    if (mode != 1) CK(hipMemcpyAsync(d_in + off, h_in + off, n, hipMemcpyHostToDevice, s1));
-                    if (mode != 0) CK(hipMemcpyAsync(h_out + off, d_out + off, n, hipMemcpyDeviceToHost, s2));
+    for (unsigned flags : {(unsigned)hipHostMallocDefault, (unsigned)(hipHostMallocPortable | hipHostMallocMapped)}) {
+        uint8_t *h_in, *h_out;
+        CK(hipHostMalloc((void **)&h_in, bytes, flags));
+        CK(hipHostMalloc((void **)&h_out, bytes, flags));
+        memset(h_in, 1, bytes);
+        memset(h_out, 1, bytes);
+        for (int pair = 0; pair < 3; pair++) {
+            hipStream_t s1, s2;
+            CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+            CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+            for (size_t piece : {(size_t)10 << 20, (size_t)20 << 20, (size_t)40 << 20})
+                for (int mode = 0; mode < 3; mode++) {
+                    CK(hipDeviceSynchronize());
+                    double t0 = now();
+                    for (size_t off = 0; off < bytes; off += piece) {
+                        size_t n = std::min(piece, bytes - off);
+                        if (mode != 1) CK(hipMemcpyAsync(d_in + off, h_in + off, n, hipMemcpyHostToDevice, s1));
+                        if (mode != 0) CK(hipMemcpyAsync(h_out + off, d_out + off, n, hipMemcpyDeviceToHost, s2));
+                    }
+                    CK(hipDeviceSynchronize());
+                    best[mode] = std::min(best[mode], now() - t0);
                 }
-                CK(hipDeviceSynchronize());
-                best[mode] = std::min(best[mode], now() - t0);
-            }
-        CK(hipStreamDestroy(s1));
-        CK(hipStreamDestroy(s2));
+            CK(hipStreamDestroy(s1));
+            CK(hipStreamDestroy(s2));
+        }
+        CK(hipHostFree(h_in));
+        CK(hipHostFree(h_out));
     }
-    CK(hipHostFree(h_in)); CK(hipHostFree(h_out)); CK(hipFree(d_in)); CK(hipFree(d_out));
+    CK(hipFree(d_in));
+    CK(hipFree(d_out));
     *h2d_alone = best[0];
     *d2h_alone = best[1];
     return best[2];
