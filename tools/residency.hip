@@ -8,6 +8,7 @@
 //
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -I hades252_amd/csrc -o build_tools/residency tools/residency.hip
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -167,7 +168,24 @@ static void sweep(const char *name, kern_t k, int block, size_t lds_need, size_t
            n / (t[t.size() / 2] * 1e-3) / 1e6, sum == g_ref ? "output ok" : "OUTPUT DIFFERS");
 }
 
-int main() {
+int main(int argc, char **argv) {
+    if (argc > 1 && strcmp(argv[1], "sizes") == 0) {
+        // batch sizes around multiples of what is resident at once: 3 blocks per CU hold 3 072 waves = 196 608 states, 4 hold
+        // 4 096 waves = 262 144; a batch slightly above a multiple runs its last blocks alone (round 4)
+        uint8_t *d;
+        unsigned long long *d_sum;
+        CHECK(hipMalloc(&d, ((size_t)1 << 26) * 160));
+        CHECK(hipMalloc(&d_sum, 8));
+        const size_t full = lds_wave_bytes(5), half = 32 * lds_rec_bytes(5);
+        for (size_t n : {(size_t)196608, (size_t)1 << 18, (size_t)3 << 17, (size_t)1 << 19, (size_t)786432, (size_t)1 << 20,
+                         (size_t)1 << 22, (size_t)1 << 24, (size_t)1 << 26}) {
+            printf("n = %zu states (%zu waves)\n", n, n / 64);
+            g_ref = 0;
+            sweep("  full slab, 3 blocks/CU (shipped)", k_perm<256, 4, 0>, 256, 4 * full, 0, d, n, d_sum);
+            sweep("  half slab, 4 blocks/CU", k_perm<256, 4, 1>, 256, 4 * half, 0, d, n, d_sum);
+        }
+        return 0;
+    }
     const size_t n = (size_t)1 << 24;
     uint8_t *d;
     unsigned long long *d_sum;
