@@ -4,7 +4,9 @@ helped lane-split kernel under timing disturbance.  Everything goes through the 
 import json
 import os
 import sys
+import random
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -434,6 +436,120 @@ def test_warm_up_prepays_the_first_call(torch_cuda, H, hades_lib, oracle):
     assert rc == -2 and H.pool_bytes() == 0
     H.warm_up(n)
     assert H.pool_bytes() == held
+
+
+def test_concurrent_callers_with_faults_flying(torch_cuda, H, hades_lib, oracle):
+    """Chaos run of the host boundary: four threads call hades252_perm_batch with batches of every path's size (staging
+    buffer, one chunk, chunk pipeline, staging threads) while the main thread keeps arming the fault hook at random sites
+    and trims the pool under their feet.  Whichever call a fault lands in: return code 0 or -2, every state its input or
+    its output (all outputs when 0), no hang, no crash -- and afterwards, hook disarmed, every size is right again."""
+    lib = hades_lib
+    sizes = [1, 200, 3000, 70000, 140000, 300000]
+    data = {n: (oracle.gen_b(1000 + n, 5 * n),) for n in sizes}
+    data = {n: (inp, oracle.perm_batch(inp)) for n, (inp,) in data.items()}
+    stop = threading.Event()
+    problems, calls, failures = [], [0], [0]
+
+    def worker(seed):
+        rng = random.Random(seed)
+        while not stop.is_set():
+            n = rng.choice(sizes)
+            inp, exp = data[n]
+            buf = inp.copy()
+            rc = lib.hades252_perm_batch(buf.ctypes.data, n)
+            calls[0] += 1
+            if rc == 0:
+                if not (buf == exp).all():
+                    problems.append(("wrong result with rc 0", n))
+            elif rc == -2:
+                failures[0] += 1
+                ok, _ = each_state_is_input_or_output(buf, inp, exp)
+                if not ok:
+                    problems.append(("torn state", n))
+            else:
+                problems.append(("return code", rc, n))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+    for t in threads:
+        t.start()
+    rng = random.Random(99)
+    t_end = time.time() + 12
+    sites = ["malloc", "hostmalloc", "memcpy", "streamcreate", "eventcreate", "sync", "thread", "hostregister"]
+    while time.time() < t_end:
+        H.fault_inject("%s:%d" % (rng.choice(sites), rng.randint(1, 12)))
+        time.sleep(rng.random() * 0.02)
+        if rng.random() < 0.2:
+            H.trim()
+    H.fault_inject(None)
+    stop.set()
+    for t in threads:
+        t.join(timeout=120)
+        assert not t.is_alive(), "a caller hangs"
+    assert not problems, problems[:5]
+    assert calls[0] > 50 and failures[0] > 5, (calls, failures)
+    for n in sizes:                                                       # hook disarmed: everything works again
+        inp, exp = data[n]
+        buf = inp.copy()
+        assert lib.hades252_perm_batch(buf.ctypes.data, n) == 0 and (buf == exp).all(), n
+    assert H.pool_bytes() <= (1 << 30)
+
+
+def test_concurrent_one_shot_callers_with_faults_flying(torch_cuda, H, hades_lib, oracle):
+    """The same chaos for the one-shot callers: three threads build Merkle roots (resident-size and staged uploads) and hash
+    sponge batches from host memory while faults are armed at random and the pool is trimmed.  A root is written on success
+    only and is then right; digests of a successful call are right; nothing hangs; afterwards everything works."""
+    lib = hades_lib
+    small = oracle.gen_b(5, 40000)
+    big = oracle.gen_b(6, 4 ** 9 + 77)                                    # > 8 MiB: staged upload
+    roots = {40000: oracle.merkle_tree(small, 4, TAG4, 1)[-1], 4 ** 9 + 77: oracle.merkle_tree(big, 4, TAG4, 1)[-1]}
+    leaves = {40000: small, 4 ** 9 + 77: big}
+    msgs = oracle.gen_b(99, 3000 * 6)
+    dig_exp = oracle.sponge(msgs, 6, CAP, 1)
+    stop = threading.Event()
+    problems, calls, failures = [], [0], [0]
+
+    def worker(seed):
+        rng = random.Random(seed)
+        while not stop.is_set():
+            calls[0] += 1
+            if rng.random() < 0.6:
+                n = rng.choice(list(roots))
+                root = np.full(4, 0xABCDEF, dtype=np.uint64)
+                rc = lib.hades252_merkle_root(leaves[n].ctypes.data, n, 4, H._tag_arr(TAG4), 1, None, root.ctypes.data)
+                if rc == 0 and not (root == roots[n]).all():
+                    problems.append(("wrong root", n))
+                if rc != 0 and not (root == 0xABCDEF).all():
+                    problems.append(("root written by a failing call", n, rc))
+            else:
+                dig = np.zeros(3000 * 4, dtype=np.uint64)
+                rc = lib.hades252_sponge_hash(msgs.ctypes.data, 3000, 6, H._tag_arr(CAP), 1, dig.ctypes.data)
+                if rc == 0 and not (dig == dig_exp).all():
+                    problems.append(("wrong digests",))
+            if rc not in (0, -2):
+                problems.append(("return code", rc))
+            failures[0] += rc != 0
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(3)]
+    for t in threads:
+        t.start()
+    rng = random.Random(7)
+    t_end = time.time() + 10
+    sites = ["malloc", "hostmalloc", "memcpy", "streamcreate", "eventcreate", "sync", "thread"]
+    while time.time() < t_end:
+        H.fault_inject("%s:%d" % (rng.choice(sites), rng.randint(1, 10)))
+        time.sleep(rng.random() * 0.02)
+        if rng.random() < 0.2:
+            H.trim()
+    H.fault_inject(None)
+    stop.set()
+    for t in threads:
+        t.join(timeout=120)
+        assert not t.is_alive(), "a caller hangs"
+    assert not problems, problems[:5]
+    assert calls[0] > 30 and failures[0] > 3, (calls, failures)
+    for n in roots:
+        assert (H.merkle_root_host(leaves[n], 4, TAG4, 1) == roots[n]).all()
+    assert (H.sponge_hash_host(msgs, 3000, 6, CAP, 1).reshape(-1) == dig_exp).all()
 
 
 def test_fault_hook_argument_checking(hades_lib):
