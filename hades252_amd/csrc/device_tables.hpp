@@ -24,11 +24,7 @@ __device__ const LanesTables d_rows = {HADES_ROWS_ROUND_INIT, HADES_FAST_FINAL_F
                                         HADES_P29, HADES_NEG_PINV29};
 // ... and K_r of its 59 partial rounds as the per-lane constants of lane_lin (the linear map by the row)
 __device__ const uint32_t d_rows_klin[59][kNL][16] = HADES_ROWS_KLIN_INIT;
-// trace kernel: U_r with mont(X_after_round_r, U_r) = x * 2^256
-__device__ const int32_t d_trace_lin[67][kLinRow] = HADES_FAST_TRACE_LIN_INIT;        // as linear maps (mont_lin)
-// ... + D_r: the partial-round constants of words 0..3 that the shipped schedule defers (hades_fast.hpp item 5)
-__device__ const uint32_t d_trace_d[67][5][8] = HADES_FAST_TRACE_D_INIT;
-// witness kernel (true-form schedule, hades252_amd/_derive.py::witness_schedule): round constants as Rp-form addends minus p
+// witness and trace kernels (true-form schedule, hades252_amd/_derive.py::witness_schedule): round constants as Rp-form addends minus p
 // (c[r]: five words of nine signed-digit limbs; c[67] = zeros), their images under the linear-layer map (ck[r], words 0..3,
 // partial rounds), and the two linear maps: in-memory limbs -> Rp form, and Y -> Y lam 2^29 (the ONE constant product of
 // the linear layer).  __constant__, not const: see d_wire_from_lin below.

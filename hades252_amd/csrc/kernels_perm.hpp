@@ -39,37 +39,6 @@ __global__ void __launch_bounds__(kBlock) k_perm_trace_literal(const uint8_t *__
     }
 }
 
-// Scale-tracked trace (the shipped one): the rounds of k_perm_fast; after each round every word is
-// brought back to the in-memory BlsScalar with ONE constant product (U_r = 2^256 * Rp / s_{r+1},
-// hades252_amd/_derive.py), a full reduction, and -- in partial rounds, whose word 0..3 constants the
-// schedule defers -- one field addition of the known offset D_r: 5 extra products per round instead of
-// the literal schedule's 28 / 40 full-width products.
-__global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__restrict__ states,
-                                                               uint8_t *__restrict__ trace, size_t n) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    uint8_t *slab = wave_slab<5>(lds);
-    size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
-    F29 st[5];
-    {
-        Fr in[5];
-        wave_load_records<5>(states, rec0, n, slab, in);
-#pragma unroll
-        for (int w = 0; w < 5; w++) st[w] = to_f29(in[w]);
-    }
-#pragma unroll 1
-    for (int r = 0; r < 67; r++) {
-        fast_round(d_fast.round[r], d_fast.lin[r], r < 4 || r >= 63, st);
-        const int32_t *u = d_trace_lin[r];
-#pragma unroll
-        for (int w = 0; w < 5; w++) {
-            Fr v = finalize(mont_lin(st[w], u));
-            if (r >= 4 && r < 63) v = fr_add(v, load_const(d_trace_d[r], w));
-            slab_put<5>(slab, w, v);
-        }
-        slab_flush<5>(trace + (size_t)r * n * 160, rec0, n, slab);
-    }
-}
-
 // Full gadget witness: EVERY gate output of the reference's GadgetStrategy for every state -- the 972 values a
 // PLONK prover assigns per permutation (src/strategies/gadget.rs:41-133: round-0 key additions, v^2 / v^4 / v^5 of
 // each S-box, and per linear layer the 3-term partial sums r1[j] and the rows r2[j] with the NEXT round's constant
@@ -257,6 +226,70 @@ __global__ void __launch_bounds__(kBlock, 5) k_perm_witness(const uint8_t *__res
 #pragma unroll
             for (int k = 0; k < kNL; k++) limb_fence(y[w].l[k]);
         wire += 10;
+    }
+}
+
+// Per-round trace, shipped form: the state after every round (reference src/strategies.rs:140-157 observed round by round;
+// what the gadget's rows are before the next round key), round-major: trace[r] is a whole AoS batch.  The rounds of
+// k_perm_witness -- every value held as x Rp, the linear layer as one constant linear map per word + the small-integer
+// rows -- with the five words of the state as the only outputs, each through finalize32, coalesced through the wave's
+// staging slab.  Rounds 2-3 ran the throughput kernel's scale-tracked rounds and un-scaled five words per round with a
+// per-round constant map + full reduction + (partial rounds) a field addition of the deferred constants: 188 k VALU
+// instructions per permutation against 154 k here.
+__global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__restrict__ states,
+                                                               uint8_t *__restrict__ trace, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<5>(lds);
+    const size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    F29 y[5];
+    {
+        Fr in[5];
+        wave_load_records<5>(states, rec0, n, slab, in);
+#pragma unroll
+        for (int w = 0; w < 5; w++) y[w] = to_f29(in[w]);
+#pragma unroll 1
+        for (int i = 0; i < 5; i++) {                   // in-memory limbs (x 2^256) -> x Rp
+            int off = 0;                                // (opaque offset: see k_perm_witness)
+            asm volatile("" : "+s"(off));
+            y[4] = mont_lin(y[4], d_wit.in_lin + off);
+            rotate_right(y);
+#pragma unroll
+            for (int w = 0; w < 5; w++)
+#pragma unroll
+                for (int k = 0; k < kNL; k++) limb_fence(y[w].l[k]);
+        }
+    }
+#pragma unroll 1
+    for (int r = 0; r < 67; r++) {
+        const int32_t *c = d_wit.c[r], *ck = d_wit.ck[r];
+        const bool full = r < 4 || r >= 63;
+        const int cnt = full ? 5 : 1;
+#pragma unroll 1
+        for (int i = 0; i < cnt; i++) {                 // S-boxes: word 4 - i rotates through y[4] in a full round
+            F29 z = y[4];
+            add_lazy(z, c + (4 - i) * kNL);
+            y[4] = sbox29(z);
+            if (full) rotate_right(y);
+#pragma unroll
+            for (int w = 0; w < 5; w++)
+#pragma unroll
+                for (int k = 0; k < kNL; k++) limb_fence(y[w].l[k]);
+        }
+#pragma unroll
+        for (int w = 0; w < 5; w++) {                   // U_w = Y_w lam 2^29 (+ the round constant seen through the map)
+            int off = 0;
+            asm volatile("" : "+s"(off));
+            y[w] = mont_lin(y[w], d_wit.k_lin + off);
+            if (w < 4 && !full) add_lazy(y[w], ck + w * kNL);
+        }
+        small_mds(y);
+#pragma unroll
+        for (int w = 0; w < 5; w++) slab_put<5>(slab, w, finalize32(y[w]));
+        slab_flush<5>(trace + (size_t)r * n * 160, rec0, n, slab);
+#pragma unroll
+        for (int w = 0; w < 5; w++)
+#pragma unroll
+            for (int k = 0; k < kNL; k++) limb_fence(y[w].l[k]);
     }
 }
 

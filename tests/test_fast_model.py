@@ -161,9 +161,8 @@ def finalize_model(x, factor):
     return v
 
 
-def fast_perm_model(mont_vals, trace=None):
-    """mont_vals: 5 integers = in-memory BlsScalar values (value * 2^256 mod p).  Returns the same.
-    `trace` (a list) receives the per-round states the way k_perm_trace_fast produces them."""
+def fast_perm_model(mont_vals):
+    """mont_vals: 5 integers = in-memory BlsScalar values (value * 2^256 mod p).  Returns the same."""
     sch = D.fast_schedule()
     st = [D.to_limbs29(v) for v in mont_vals]
     for r in range(D.ROUNDS):
@@ -181,9 +180,6 @@ def fast_perm_model(mont_vals, trace=None):
         st = small_mds(st)
         for x in st:
             assert normalised(x)
-        if trace is not None:
-            trace.append([(finalize_model(x, sch["trace_u"][r]) + sch["trace_d"][r][w] * S.R) % P
-                          for w, x in enumerate(st)])
     out = []
     for x in st:
         v = val(mont_lin(x, sch["final_f"]))
@@ -251,19 +247,6 @@ def test_model_matches_spec_oracle():
     for vals in cases:
         got = fast_perm_model([S.to_mont(v) for v in vals])
         assert got == [S.to_mont(v) for v in S.perm(vals)]
-
-
-def test_trace_model_matches_spec_oracle():
-    """k_perm_trace_fast: un-scaling factor U_r and deferred-constant offset D_r per round."""
-    rng = random.Random(31)
-    for vals in ([1] * 5, [P - 1, 0, 1, P - 2, 2], [rng.randrange(P) for _ in range(5)]):
-        tr, spec_tr = [], []
-        out = fast_perm_model([S.to_mont(v) for v in vals], tr)
-        S.perm(vals, spec_tr)
-        assert len(tr) == 67
-        for r in range(67):
-            assert tr[r] == [S.to_mont(v) for v in spec_tr[r]], r
-        assert tr[66] == out
 
 
 def small_mds_row(i, st):
@@ -363,8 +346,8 @@ def add_lazy(x, c):
     return r
 
 
-def witness_model(mont_vals):
-    """Limb-exact replay of k_perm_witness (kernels_perm.hpp): the TRUE-FORM schedule of
+def witness_model(mont_vals, trace=None):
+    """Limb-exact replay of k_perm_witness and k_perm_trace_fast (kernels_perm.hpp): the TRUE-FORM schedule of
     hades252_amd/_derive.py::witness_schedule -- every held value is x * Rp, Montgomery products are closed in that form,
     the linear layer is one constant linear map per word (U = Y lam 2^29) + the small-integer rows + the one-limb step,
     and every gate output of the reference's GadgetStrategy leaves through finalize32 (the exact division by 32)."""
@@ -393,6 +376,8 @@ def witness_model(mont_vals):
             wires.append(None)                                              # r2[j]: after the rows
         y = small_mds(u)
         assert y == [mds_row_cols(u, j, 5) for j in range(5)]
+        if trace is not None:                                                   # k_perm_trace_fast: the same rounds, the
+            trace.append([finalize32_model(x) for x in y])                      # state after the round as the only output
         for j in range(5):
             wires[len(wires) - 10 + 2 * j + 1] = finalize32_model(add_lazy(y[j], c[r + 1][j]))
     # gate order: in a full round the S-box gates come word 0 first
@@ -415,6 +400,19 @@ def test_witness_model_matches_gadget_schedule():
         assert len(got) == len(spec) == 972
         bad = [i for i in range(972) if got[i] != S.to_mont(spec[i])]
         assert not bad, bad[:10]
+
+
+def test_trace_model_matches_spec_oracle():
+    """k_perm_trace_fast: the true-form rounds with the five words after every round as outputs (finalize32 each)."""
+    rng = random.Random(31)
+    for vals in ([1] * 5, [P - 1, 0, 1, P - 2, 2], [0] * 5, [rng.randrange(P) for _ in range(5)]):
+        tr, spec_tr = [], []
+        witness_model([S.to_mont(v) for v in vals], tr)
+        out = S.perm(vals, spec_tr)
+        assert len(tr) == 67
+        for r in range(67):
+            assert tr[r] == [S.to_mont(v) for v in spec_tr[r]], r
+        assert tr[66] == [S.to_mont(v) for v in out]
 
 
 def test_finalize32_window_adversarial():
