@@ -365,8 +365,8 @@ def host_path_record(log_n: int = 22):
     rec["entry_point"] = ("hades252_perm_batch on page-locked host memory from hades252_host_alloc: chunks copied in, "
                           "permuted and copied out on three streams chained by events (native C++ caller, system HIP "
                           "runtime)")
-    rec["ceiling"] = ("hipMemcpyAsync of the same bytes in both directions at once (20 MiB pieces, page-locked memory, "
-                      "best of 4 stream pairs), measured by the same process in this run")
+    rec["ceiling"] = ("hipMemcpyAsync of the same bytes in both directions at once (10 / 20 / 40 MiB pieces, both kinds of "
+                      "page-locked memory, best of 3 stream pairs each), measured by the same process in this run")
     return rec
 
 
