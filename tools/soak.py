@@ -55,4 +55,17 @@ for it in range(12):
         bad += 1
         print("MISMATCH host merkle it=%d n=%d" % (it, n))
 print("host paths: 12 rounds, total mismatches:", bad)
+# gadget witness / per-round trace (true-form rounds) against the throughput kernel and each other, ragged sizes
+for it in range(24):
+    n = int(torch.randint(1, 5000, (1,)).item())
+    a = H.gen_b(5 * n, "cuda", first_elem=it * 65537).view(n, 5, 4)
+    ref = a.clone()
+    fast.perm(ref)
+    w = H.perm_witness(a)
+    tr = H.perm_trace(a)
+    last = torch.stack([w[962 + 2 * j + 1] for j in range(5)], dim=1)
+    if not (torch.equal(last, ref) and torch.equal(tr[66], ref)):
+        bad += 1
+        print("MISMATCH witness / trace vs perm it=%d n=%d" % (it, n))
+print("witness / trace: 24 batches, total mismatches:", bad)
 sys.exit(1 if bad else 0)
