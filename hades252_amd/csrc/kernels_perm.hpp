@@ -120,7 +120,58 @@ __device__ __forceinline__ F29 mds_row_cols(const int32_t *crow, const F29 (&u)[
     return y;
 }
 
-__global__ void __launch_bounds__(kBlock, 5) k_perm_witness(const uint8_t *__restrict__ states,
+// mont_lin (hades_fast.hpp) on NW words of a state with ONE walk over the table: the nine multipliers of a column arrive
+// once (scalar loads, a column ahead) and serve NW accumulators -- 1/NW of the scalar-load traffic of separate maps, and NW
+// independent multiply-add chains for the scheduler to interleave.  Word for word the same operations in the same order
+// as mont_lin, hence the same limbs.  (All five words at once need 2 x 45 registers for operands and results: the callers
+// go 3 + 2.)
+template <int NW>
+__device__ __forceinline__ void mont_lin_words(F29 *a, const int32_t *e) {
+    int32_t m0[NW], m1[NW];
+    F29 r[NW];
+    int64_t acc[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) acc[w] = 0;
+    int32_t cur[kNL], nxt[kNL];
+#pragma unroll
+    for (int k = 0; k < kNL; k++) cur[k] = e[k];
+#pragma unroll
+    for (int j = 0; j < kNL; j++) {
+        if (j + 1 < kNL) {
+#pragma unroll
+            for (int k = 0; k < kNL; k++) nxt[k] = e[kNL * (j + 1) + k];
+        }
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+#pragma unroll
+            for (int k = 0; k < kNL; k++) mac(acc[w], a[w].l[k], cur[k]);
+            if (j >= 1) mac(acc[w], m0[w], NEGP29[j]);
+            if (j >= 2) mac(acc[w], m1[w], NEGP29[j - 1]);
+            const int32_t low = (int32_t)((uint32_t)acc[w] & kMask29);
+            if (j == 0)
+                m0[w] = low;
+            else if (j == 1)
+                m1[w] = low;
+            else
+                r[w].l[j - 2] = low;
+            acc[w] >>= kLB;
+            asm volatile("" : "+v"(acc[w]));            // ties the `pin` statements of this column to the data flow (see
+        }                                               // mont_mul_small: left floating they keep every partial sum alive)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < kNL; k++) cur[k] = nxt[k];
+    }
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        mac(acc[w], m1[w], NEGP29[kNL - 1]);
+        r[w].l[kNL - 2] = (int32_t)((uint32_t)acc[w] & kMask29);
+        acc[w] >>= kLB;
+        r[w].l[kNL - 1] = (int32_t)acc[w];
+        a[w] = r[w];
+    }
+}
+
+__global__ void __launch_bounds__(kBlock, 3) k_perm_witness(const uint8_t *__restrict__ states,
                                                             uint8_t *__restrict__ wires, size_t n) {
     const size_t rec = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = rec < n;
@@ -196,12 +247,17 @@ __global__ void __launch_bounds__(kBlock, 5) k_perm_witness(const uint8_t *__res
         wire += 3 * cnt;
         // the constant product of the linear layer, U_w = Y_w lam 2^29; in a partial round words 0..3 carry their round
         // constant through the map as an addend
+        {
+            int off = 0;                                // an offset the compiler cannot see through: the 81 multipliers are
+            asm volatile("" : "+s"(off));               // NOT to be hoisted out of the round loop (as 64-bit values: SGPR
+            mont_lin_words<3>(y, d_wit.k_lin + off);    // spills, every product widened)
+            int off2 = 0;
+            asm volatile("" : "+s"(off2));
+            mont_lin_words<2>(y + 3, d_wit.k_lin + off2);
+            if (!full) {
 #pragma unroll
-        for (int w = 0; w < 5; w++) {
-            int off = 0;                                // an offset the compiler cannot see through, per use: the 81
-            asm volatile("" : "+s"(off));               // multipliers are NOT to be hoisted out of the round loop or shared
-            y[w] = mont_lin(y[w], d_wit.k_lin + off);   // between the five maps (as 64-bit values: SGPR spills, widened products)
-            if (w < 4 && !full) add_lazy(y[w], ck + w * kNL);
+                for (int w = 0; w < 4; w++) add_lazy(y[w], ck + w * kNL);
+            }
         }
         // the linear layer over U = y.  r1[j]: columns 0..2 of row j, a gate output only; then the rows themselves in
         // place (small_mds, limb-major: no second copy of the state); r2[j] = row j + the next round's constant
@@ -275,12 +331,17 @@ __global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__
 #pragma unroll
                 for (int k = 0; k < kNL; k++) limb_fence(y[w].l[k]);
         }
-#pragma unroll
-        for (int w = 0; w < 5; w++) {                   // U_w = Y_w lam 2^29 (+ the round constant seen through the map)
+        {                                               // U_w = Y_w lam 2^29 (+ the round constants seen through the map)
             int off = 0;
             asm volatile("" : "+s"(off));
-            y[w] = mont_lin(y[w], d_wit.k_lin + off);
-            if (w < 4 && !full) add_lazy(y[w], ck + w * kNL);
+            mont_lin_words<3>(y, d_wit.k_lin + off);
+            int off2 = 0;
+            asm volatile("" : "+s"(off2));
+            mont_lin_words<2>(y + 3, d_wit.k_lin + off2);
+            if (!full) {
+#pragma unroll
+                for (int w = 0; w < 4; w++) add_lazy(y[w], ck + w * kNL);
+            }
         }
         small_mds(y);
 #pragma unroll

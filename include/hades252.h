@@ -205,7 +205,7 @@ int hades252_sponge_hash_var(const uint64_t *scalars, size_t n_scalars, const ui
  * d_states is not modified.  Needs 67 * 160 * n_perms bytes. */
 int hades252_perm_trace_dev(const void *d_states, void *d_trace, size_t n_perms, void *stream);
 /* kernel: HADES252_KERNEL_FAST (default; radix-2^29 rounds that hold every value in true form, so a round's five words
- * leave through an exact division by 32: ~190 M permutations/s) or HADES252_KERNEL_LITERAL (the reference's schedule,
+ * leave through an exact division by 32: ~200 M permutations/s) or HADES252_KERNEL_LITERAL (the reference's schedule,
  * ~35 M/s); identical bits. */
 int hades252_perm_trace_dev_ex(const void *d_states, void *d_trace, size_t n_perms, void *stream, int kernel);
 

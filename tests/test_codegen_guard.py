@@ -98,7 +98,7 @@ def test_witness_kernel_products_stay_single_multiply_adds(device_asm):
     it was written and would again silently: (i) a loop-invariant linear-map table is hoisted out of the loop as 81 64-bit
     values (SGPR spills, every product widened), (ii) a limb whose sign extension was computed in an earlier basic block is
     multiplied as a 64-bit value (v_mul_lo_u32 pairs around a v_mad_u64_u32).  One multiply-add per limb product:
-    6 linear maps (97: the input's, rolled, + five unrolled) + S-box (117 + 117 + 153) + r1 row (35) + rows (265) + 10
+    6 linear maps (97: the input's, rolled, + five in two grouped walks over the table) + S-box (117 + 117 + 153) + r1 row (35) + rows (265) + 10
     finalize32 (9) = 1359."""
     bodies, res = device_asm
     (name,) = find(bodies, "k_perm_witness")
@@ -109,7 +109,7 @@ def test_witness_kernel_products_stay_single_multiply_adds(device_asm):
     assert widened <= 16, "%d v_mul_lo_u32 (store addresses account for ~7): limb products are being widened to 64 x 32 bits" % widened
     assert "flat_load" not in body and "scratch_" not in body
     r = res[name]
-    assert r["SGPRs Spill"] == 0 and r["VGPRs"] <= 112, r
+    assert r["SGPRs Spill"] == 0 and r["VGPRs"] <= 168 and r["ScratchSize"] == 0, r      # (three waves per SIMD: enough, measured)
 
 
 def test_perm_lanes_instruction_mix(device_asm):
