@@ -132,14 +132,17 @@ __device__ __forceinline__ void mont_lin_words(F29 *a, const int32_t *e) {
     int64_t acc[NW];
 #pragma unroll
     for (int w = 0; w < NW; w++) acc[w] = 0;
-    int32_t cur[kNL], nxt[kNL];
+    int32_t cur[kNL], nxt[kNL], nx2[kNL];               // the multipliers travel TWO columns ahead of their use
 #pragma unroll
-    for (int k = 0; k < kNL; k++) cur[k] = e[k];
+    for (int k = 0; k < kNL; k++) {
+        cur[k] = e[k];
+        nxt[k] = e[kNL + k];
+    }
 #pragma unroll
     for (int j = 0; j < kNL; j++) {
-        if (j + 1 < kNL) {
+        if (j + 2 < kNL) {
 #pragma unroll
-            for (int k = 0; k < kNL; k++) nxt[k] = e[kNL * (j + 1) + k];
+            for (int k = 0; k < kNL; k++) nx2[k] = e[kNL * (j + 2) + k];
         }
 #pragma unroll
         for (int w = 0; w < NW; w++) {
@@ -159,7 +162,10 @@ __device__ __forceinline__ void mont_lin_words(F29 *a, const int32_t *e) {
         }                                               // mont_mul_small: left floating they keep every partial sum alive)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < kNL; k++) cur[k] = nxt[k];
+        for (int k = 0; k < kNL; k++) {
+            cur[k] = nxt[k];
+            nxt[k] = nx2[k];
+        }
     }
 #pragma unroll
     for (int w = 0; w < NW; w++) {
