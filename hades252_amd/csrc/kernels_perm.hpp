@@ -325,6 +325,10 @@ __global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__
     for (int r = 0; r < 67; r++) {
         const int32_t *c = d_wit.c[r], *ck = d_wit.ck[r];
         const bool full = r < 4 || r >= 63;
+        // touch the lines of the NEXT round's addends now (26 KB of them do not stay in the scalar cache while the waves of
+        // a CU sit in different rounds); consumed after the S-boxes, so the misses travel behind ~2 000 cycles of products
+        const int32_t *cq = d_wit.c[r + 1], *ckq = d_wit.ck[r < 66 ? r + 1 : 66];
+        const int32_t warm = cq[0] | cq[16] | cq[32] | ckq[0] | ckq[16] | ckq[32];
         const int cnt = full ? 5 : 1;
 #pragma unroll 1
         for (int i = 0; i < cnt; i++) {                 // S-boxes: word 4 - i rotates through y[4] in a full round
@@ -337,6 +341,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__
 #pragma unroll
                 for (int k = 0; k < kNL; k++) limb_fence(y[w].l[k]);
         }
+        asm volatile("" ::"s"(warm));
         {                                               // U_w = Y_w lam 2^29 (+ the round constants seen through the map)
             int off = 0;
             asm volatile("" : "+s"(off));
