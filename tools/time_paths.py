@@ -231,12 +231,13 @@ def sec_wire():
             print("perm_trace %-7s n=2^%d states  %8.3f ms  %8.2f Mperm/s  (67 x 160 B written per state: %.1f GB/s)" % (name, lognt, dt * 1e3, nt / dt / 1e6, 67 * 160 * nt / dt / 1e9))
         del trace
 
-    nw = 1 << 18
-    st = H.gen_b(5 * nw, dev)
-    wires = torch.empty((972, nw, 4), dtype=torch.int64, device=dev)
-    dt = timed(lambda: H.perm_witness(st, out=wires), reps=3)
-    print("perm_witness (972 gadget wires) n=2^18 states  %8.3f ms  %8.2f Mperm/s  (31 104 B written per state: %.1f GB/s)" % (dt * 1e3, nw / dt / 1e6, 972 * 32 * nw / dt / 1e9))
-    del wires
+    for lognw in (18, 20):
+        nw = 1 << lognw
+        st = H.gen_b(5 * nw, dev)
+        wires = torch.empty((972, nw, 4), dtype=torch.int64, device=dev)
+        dt = timed(lambda: H.perm_witness(st, out=wires), reps=3)
+        print("perm_witness (972 gadget wires) n=2^%d states  %8.3f ms  %8.2f Mperm/s  (31 104 B written per state: %.1f GB/s)" % (lognw, dt * 1e3, nw / dt / 1e6, 972 * 32 * nw / dt / 1e9))
+        del wires
 
 
 def sec_perop():
