@@ -44,6 +44,7 @@ def test_bench_single_and_two_ranks_agree():
         assert wf[k]["roofline"]["bound"] == "hbm" and 0.3 < wf[k]["roofline"]["frac"] < 1.0
     gw = one["secondary"]["gadget_witness"]                           # f4: 972 wires per state, priced against HBM
     assert gw["last_rows_equal_perm"] is True and gw["roofline"]["bound"] == "hbm" and 0.15 < gw["roofline"]["frac"] < 1.0
+    assert gw["trace"]["last_round_equals_perm"] is True and 0.1 < gw["trace"]["roofline"]["frac"] < 1.0
     assert 0 < hp["pageable_ms"] < 3 * hp["ms"]                       # ordinary memory on fresh pages: staging threads
     assert one["config"]["kernel"] == "k_perm_fast" and "valu_issue" in one and "frac_of_measured" not in one["valu_issue"]
     assert one["n_gpus"] == 1 and one["parity_vs_cpu_sample"] is True
