@@ -176,7 +176,7 @@ def sec_host():
         for _ in range(3):
             t0 = time.perf_counter(); s.perm(plain); ts.append(time.perf_counter() - t0)
         dt = sorted(ts[1:])[len(ts[1:]) // 2]
-        print("n=2^%-2d host path, pageable memory (page-locked and released inside every call) %9.3f ms  %8.2f Mperm/s  %.2f GB/s each way"
+        print("n=2^%-2d host path, pageable memory (through the staging threads; in-process numbers: see host_path_native.txt) %9.3f ms  %8.2f Mperm/s  %.2f GB/s each way"
               % (logn, dt * 1e3, n / dt / 1e6, nbytes / dt / 1e9))
         for w in (2, 8):
             with H.HostBuffer(n) as hb:
