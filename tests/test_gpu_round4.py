@@ -473,7 +473,7 @@ def test_concurrent_callers_with_faults_flying(torch_cuda, H, hades_lib, oracle)
     for t in threads:
         t.start()
     rng = random.Random(99)
-    t_end = time.time() + 12
+    t_end = time.time() + float(os.environ.get("HADES252_CHAOS_SECONDS", "12"))
     sites = ["malloc", "hostmalloc", "memcpy", "streamcreate", "eventcreate", "sync", "thread", "hostregister"]
     while time.time() < t_end:
         H.fault_inject("%s:%d" % (rng.choice(sites), rng.randint(1, 12)))
@@ -533,7 +533,7 @@ def test_concurrent_one_shot_callers_with_faults_flying(torch_cuda, H, hades_lib
     for t in threads:
         t.start()
     rng = random.Random(7)
-    t_end = time.time() + 10
+    t_end = time.time() + float(os.environ.get("HADES252_CHAOS_SECONDS", "10"))
     sites = ["malloc", "hostmalloc", "memcpy", "streamcreate", "eventcreate", "sync", "thread"]
     while time.time() < t_end:
         H.fault_inject("%s:%d" % (rng.choice(sites), rng.randint(1, 10)))
