@@ -32,6 +32,15 @@ Also in the line:
                 `host_path`: the entry point a
                 Rust `Strategy::perm` binds (`hades252_perm_batch`: host memory in, host memory out,
                 PCIe-inclusive) on 2^22 states against this box's measured bidirectional copy ceiling.
+  dist          N > 1 evidence: backend, ranks_seen (= the process group's world size), the physical device every rank
+                sat on (PCI address / UUID, gathered) -- two ranks on one device fail the job unless --single-device.
+                With N > 1 every rank also takes part in two more records under `secondary`:
+                `config5` (BASELINE configs[4] at world size 8: 2^27 states per GPU, 3 timed launches, oracle samples on
+                every rank, the sum of the shard digests against the committed digest of the one-device 2^30 run) and
+                `merkle_2p24_sharded` (the 2^24-leaf tree sharded by sub-tree: local sub-roots, ONE all_gather of 32-byte
+                sub-roots -- the path's only exchange step -- and the top levels; root against the oracle's committed root).
+  crossover     under `secondary`: the smallest batch for which one hades252_perm_batch call beats the CPU port
+                (one core / all cores) -- the reference's own call shape is ONE permutation per call (README.md:60-61).
 `--workload merkle` times the tree build itself as the step (development; the driver runs the default).
 """
 from __future__ import annotations
@@ -53,7 +62,7 @@ HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak, MI355X_MICROARCH.md
 MADS_PER_PERM = 99 * 387 + 59 * 89 + 5 * 97 + 67 * 265       # 64-bit multiply-adds: S-boxes, K_r, FINAL_F, linear layers
 SHIFTS_PER_PERM = 17 * 297 + 9 * 59 + 10 * 5 + 45 * 67       # 64-bit arithmetic shifts, one per column: same issue class
 OPS64_PER_PERM = MADS_PER_PERM + SHIFTS_PER_PERM
-OPS32_PER_PERM = 83945 - OPS64_PER_PERM                      # 32-bit ops
+# (32-bit operations = `valu_instructions_per_wave` of the keyed profile record - OPS64_PER_PERM: never a literal here)
 N_SIMD = 1024
 PEAK_CLOCK_HZ = 2.4e9
 # Issue model: a wave64 instruction occupies its SIMD-16 for 4 cycles when 64-bit, 2 cycles when 32-bit
@@ -391,6 +400,192 @@ def host_path_record(log_n: int = 22):
     return rec
 
 
+def profile_record(build, kernel_name: str, n: int):
+    """The committed rocprofv3 PMC record of the dominant kernel (profiles/hbm_traffic.json, written by
+    tools/summarize_profile.py on the GPU box and stamped with the commit by tools/collect_profiles.sh) -- only while it is
+    keyed to the very kernel this process runs: same sources + tables + flags (`build.perm_fast_hash()`), same launch
+    size.  Returns (record or None, device-record or None): the second is the per-kernel table of the other kernels
+    (`secondary_kernels`), keyed by `build.device_source_hash()`."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        rec = json.load(open(tpath))
+    except Exception:
+        return None, None
+    main_rec = None
+    if (kernel_name == "k_perm_fast" and rec.get("kernel") == "k_perm_fast"
+            and rec.get("kernel_source_hash") == build.perm_fast_hash() and "hash_note" not in rec):
+        main_rec = dict(rec)
+        if rec.get("perms_per_launch") != n:          # instructions per wave do not depend on the launch size, bytes do
+            main_rec["hbm_bytes_per_launch"] = None
+    sec = rec.get("secondary_kernels")
+    if not (isinstance(sec, dict) and sec.get("device_source_hash") == build.device_source_hash()):
+        sec = None
+    return main_rec, sec
+
+
+def attach_traffic(roofline: dict, sec, key: str, algorithmic: float):
+    """Counter-backed HBM bytes of a secondary kernel (per launch / per tree, like `achieved`), replayed from the keyed
+    record; null when the record does not belong to this build."""
+    ent = (sec or {}).get(key)
+    if ent and ent.get("hbm_bytes"):
+        roofline["traffic"] = ent["hbm_bytes"]
+        roofline["traffic_over_algorithmic"] = ent["hbm_bytes"] / algorithmic
+        roofline["traffic_source"] = ("NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of commit %s "
+                                      "(profiles/hbm_traffic.json secondary_kernels.%s), same device sources"
+                                      % (str(sec.get("measured_at_commit"))[:12], key))
+    else:
+        roofline["traffic"] = None
+
+
+def config5_record(args, H, torch, device, sharding, rank, world):
+    """BASELINE configs[4] on the ranks of this job (every rank calls this): 2^27 states per GPU at world size 8 (2^30 in
+    all), 3 timed launches, 2 048 states of every rank's shard against the CPU oracle, and the wrapping sum of the shard
+    digests after the FIRST launch against the digest of the same 2^30 outputs computed on ONE device
+    (tests/golden/kat.json `config5_2p30`).  At any other world size (the one-GPU rehearsal of this path) the shard is
+    --perms-per-gpu states and rank 0 computes the one-device digest itself when the whole range is small."""
+    n = (1 << 27) if world == 8 else (args.perms_per_gpu or (1 << 20))
+    total = n * world
+    first_perm, _ = sharding.weak_shard(rank, n)
+    st = torch.empty((n, 5, 4), dtype=torch.int64, device=device)
+    H.gen_b(5 * n, device, first_elem=5 * first_perm, out=st.view(-1, 4))
+    check = ShardCheck(torch, st, first_perm, n, args.verify_sample)
+    strat = H.ScalarStrategy(args.kernel)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+    digest1 = None
+    torch.cuda.synchronize()
+    sharding.barrier(device)
+    t0 = time.perf_counter()
+    for i, (a, b) in enumerate(evs):
+        a.record()
+        strat.perm(st)
+        b.record()
+        if i == 0:
+            digest1 = H.digest(st, first_index=20 * first_perm)       # (outside the events, inside the wall clock)
+    torch.cuda.synchronize()
+    sharding.barrier(device)
+    wall = sharding.reduce_max(time.perf_counter() - t0, device)
+    ms = sharding.gather_floats(sum(a.elapsed_time(b) for a, b in evs) / 3, device)
+    ok = sharding.reduce_min_int(1 if check.after(3) else 0, device) == 1
+    combined = ["%016x" % d for d in sharding.combine_digests(digest1, device)]
+    del st
+    torch.cuda.empty_cache()
+    gold, gold_src = None, None
+    if total == 1 << 30 and n == 1 << 27:
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
+                gold = json.load(f)["config5_2p30"]["digest"]
+            gold_src = "tests/golden/kat.json config5_2p30 (the whole 2^30 batch permuted on ONE device)"
+        except Exception:
+            gold = None
+    elif total <= 1 << 24 and rank == 0:
+        whole = H.gen_b(5 * total, device)
+        H.ScalarStrategy(args.kernel).perm(whole)
+        gold = ["%016x" % (d & 0xFFFFFFFFFFFFFFFF) for d in H.digest(whole, first_index=0)]
+        gold_src = "the same %d states permuted as ONE batch on rank 0's device in this run" % total
+        del whole
+        torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    return {"workload": "%d states per GPU x %d GPUs = %s states (BASELINE configs[4]%s), generator B, in place, 3 timed "
+                        "launches" % (n, world, ("2^%d" % (total.bit_length() - 1)) if total & (total - 1) == 0 else str(total),
+                                      "" if total == 1 << 30 else " at rehearsal size"),
+            "perms_per_gpu": n, "total_perms": total, "kernel": kernel_of(args.kernel, n),
+            "kernel_ms_per_rank": ms, "perms_per_s_per_rank": [n / (x * 1e-3) for x in ms],
+            "value": total / (max(ms) * 1e-3), "unit": "permutations/s (whole node, slowest rank's mean launch)",
+            "wall_s_3_launches_and_digest": wall,
+            "parity_vs_cpu_sample": ok, "digest": combined,
+            "digest_matches_one_device": None if gold is None else combined == list(gold), "golden": gold_src}
+
+
+def merkle_sharded_record(H, torch, device, sharding, rank, world, log_leaves=24, reps=5):
+    """BASELINE configs[3] sharded by sub-tree (every rank calls this): rank g generates the leaves
+    [g n / W, (g + 1) n / W) of the 2^24-leaf tree, builds the roots of its whole sub-trees (no communication), ONE
+    all_gather moves the 32-byte sub-roots -- the path's only exchange step -- and every rank hashes the top levels.
+    tree_ms = median over `reps` of the max over ranks of (barrier -> root in hand), the all_gather included."""
+    from hades252_amd import merkle
+    n = 1 << log_leaves
+    p_mod = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    tag = 15 * ((1 << 256) % p_mod) % p_mod
+    per_sub, subs = merkle.subtree_split(n, world)
+    shard = H.gen_b(n // world, device, first_elem=rank * (n // world))
+    root = merkle.merkle4_root_sharded(shard, n, tag, 1)                      # warm-up (code object, communicator)
+    ms = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        sharding.barrier(device)
+        t0 = time.perf_counter()
+        root = merkle.merkle4_root_sharded(shard, n, tag, 1)
+        torch.cuda.synchronize()
+        ms.append(sharding.reduce_max((time.perf_counter() - t0) * 1e3, device))
+    root_hex = "".join("%016x" % (int(v) & 0xFFFFFFFFFFFFFFFF) for v in reversed(root.cpu().tolist()))
+    gold = golden_merkle_root(n)
+    mine_ok = 1 if (gold is None or int(root_hex, 16) == gold) else 0
+    all_ok = sharding.reduce_min_int(mine_ok, device) == 1                  # every rank holds the root: all must agree
+    del shard
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    med = sorted(ms)[len(ms) // 2]
+    nodes = (n - 1) // 3
+    ach = MERKLE_BYTES_PER_NODE * nodes / (med * 1e-3) / 1e9
+    return {"workload": "arity-4 Poseidon Merkle tree over 2^%d leaves sharded over %d ranks: %d sub-tree(s) of %d leaves "
+                        "per rank, one all_gather of %d sub-roots (32 B each), top levels on every rank"
+                        % (log_leaves, world, subs, per_sub, subs * world),
+            "exchange": "all_gather, %s backend, %d bytes in all" % (sharding.backend_name(), 32 * subs * world),
+            "tree_ms": med, "tree_ms_all": ms, "nodes": nodes, "nodes_per_s": nodes / (med * 1e-3), "root": root_hex,
+            "root_matches_golden": None if gold is None else all_ok,
+            "golden": "tests/golden/kat.json merkle4_full_size (C oracle, %d permutations)" % nodes,
+            "timing": "wall clock from a barrier to the root on every rank (device synchronised), max over ranks, median "
+                      "of %d; includes the all_gather and, on one shared device (--single-device), the ranks' serialisation"
+                      % reps,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_node": MERKLE_BYTES_PER_NODE,
+                         "note": "whole-job figure against ONE device's peak x %d" % world}}
+
+
+def crossover_record(H, cb):
+    """The reference's real call shape is ONE permutation per call (README.md:60-61).  From what this run measured: the time
+    of one hades252_perm_batch call on n states in ordinary host memory (n = 1 .. 4 096, median of 21 calls), against n
+    permutations on one core of the CPU port and against n spread over all its cores; the crossover is the smallest n from
+    which the GPU call wins for every larger n measured."""
+    import numpy as np
+    strat = H.ScalarStrategy()
+    one_core = 1e6 / cb["single_thread_value"]                     # us per permutation, one thread
+    all_cores = 1e6 / cb["value"]                                  # us per permutation, all threads busy
+    sizes = [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 128, 256, 512, 1024, 4096]
+    rows = []
+    rng = np.random.default_rng(5)
+    for n in sizes:
+        host = rng.integers(0, 1 << 62, size=20 * n, dtype=np.uint64)
+        for _ in range(3):
+            strat.perm(host)
+        ts = []
+        for _ in range(21):
+            t0 = time.perf_counter()
+            strat.perm(host)
+            ts.append((time.perf_counter() - t0) * 1e6)
+        rows.append({"n": n, "gpu_call_us": sorted(ts)[10], "cpu_one_core_us": n * one_core,
+                     "cpu_all_cores_us": max(one_core, n * all_cores)})
+
+    def first_win(key):
+        win = None
+        for r in reversed(rows):
+            if r["gpu_call_us"] < r[key]:
+                win = r["n"]
+            else:
+                break
+        return win
+    return {"workload": "one hades252_perm_batch call on n states in ordinary host memory (PCIe-inclusive), median of 21",
+            "cpu": "the C port of the reference CPU path: %.1f us per permutation on one core, %.2f us with all %d cores busy "
+                   "(a batch smaller than the core count costs one permutation's time)" % (one_core, all_cores, cb["cores"]),
+            "rows": rows,
+            "gpu_beats_one_core_from_n": first_win("cpu_one_core_us"),
+            "gpu_beats_all_cores_from_n": first_win("cpu_all_cores_us"),
+            "note": "below the first figure a literal drop-in under an un-batched caller is a slow-down: keep ScalarStrategy "
+                    "there and batch (INTEGRATION.md, 'when NOT to route through HipStrategy')"}
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -438,6 +633,17 @@ def main():
                   flush=True)
             raise SystemExit(3)
 
+    # N ranks must sit on N distinct physical devices: every rank's PCI address / UUID, gathered
+    devices = sharding.gather_strings(sharding.device_identity(torch, dev_index), device)
+    ranks_seen = sharding.world_size()
+    if ranks_seen != world:
+        raise SystemExit("bench.py: rank %d: process group has %d ranks, WORLD_SIZE says %d" % (rank, ranks_seen, world))
+    if world > 1 and not args.single_device and not sharding.distinct_devices(devices):
+        if rank == 0:
+            print("bench.py: two ranks report the same physical device (pass --single-device to allow it): %r" % devices,
+                  file=sys.stderr, flush=True)
+        raise SystemExit(4)
+
     if args.workload == "merkle":
         return bench_merkle(args, H, torch, device, sharding, rank, world)
 
@@ -474,26 +680,31 @@ def main():
     all_ok = sharding.reduce_min_int(1 if rank_ok else 0, device) == 1
     digest = sharding.combine_digests(H.digest(states, first_index=20 * first_perm), device)
 
+    del states, check
+    torch.cuda.empty_cache()
+    # the records every rank takes part in (N > 1): configs[4] and the sharded tree with its one exchange step
+    multi = {}
+    if world > 1 and not args.no_secondary:
+        for name, fn in (("config5", lambda: config5_record(args, H, torch, device, sharding, rank, world)),
+                         ("merkle_2p24_sharded", lambda: merkle_sharded_record(H, torch, device, sharding, rank, world))):
+            try:
+                multi[name] = fn()
+            except ValueError as e:          # a world size the tree does not split over: the same on every rank, no collective left open
+                multi[name] = {"error": repr(e)}
     if rank != 0:
         if not rank_ok:
             raise SystemExit("rank %d: GPU output differs from the CPU oracle" % rank)
         return
-    del states
-    torch.cuda.empty_cache()
     total_perms = n * world * args.steps
     value = total_perms / elapsed
     achieved = ALGO_BYTES_PER_PERM * n / (kernel_ms_max * 1e-3) / 1e9
     traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if kernel_name == "k_perm_fast" and os.path.exists(tpath):
-        try:
-            rec = json.load(open(tpath))
-            if rec.get("perms_per_launch") == n and rec.get("kernel_source_hash") == build.perm_fast_hash():
-                traffic = rec.get("hbm_bytes_per_launch")
-                traffic_source = ("NOT measured in this run: replayed from the committed rocprofv3 PMC passes "
-                                  "(profiles/hbm_traffic.json, same kernel source hash %s)" % build.perm_fast_hash()[:12])
-        except Exception:
-            traffic = None
+    prof, sec_prof = profile_record(build, kernel_name, n)
+    if prof and prof.get("hbm_bytes_per_launch"):
+        traffic = prof.get("hbm_bytes_per_launch")
+        traffic_source = ("NOT measured in this run: replayed from the rocprofv3 PMC passes of commit %s "
+                          "(profiles/hbm_traffic.json; same kernel source hash %s, same launch size)"
+                          % (str(prof.get("measured_at_commit"))[:12], build.perm_fast_hash()[:12]))
     pow2 = n & (n - 1) == 0
     out = {
         "metric": "Hades252 permutations/sec (WIDTH=5, BLS12-381 Fr)",
@@ -509,7 +720,11 @@ def main():
                    "sharding": "contiguous range per rank, no collective"},
         "per_gpu": {"value": value / world, "unit": "permutations/s",
                     "kernel_ms_per_rank": per_rank_ms,
-                    "perms_per_s_per_rank": [n / (ms * 1e-3) for ms in per_rank_ms]},
+                    "perms_per_s_per_rank": [n / (ms * 1e-3) for ms in per_rank_ms],
+                    "device": devices},
+        "dist": {"backend": sharding.backend_name(), "ranks_seen": ranks_seen, "world_size_env": world,
+                 "distinct_devices": sharding.distinct_devices(devices), "single_device": bool(args.single_device),
+                 "data_path_collectives": "none (bookkeeping only: barrier, max of times, AND of checks, sum of digests)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": kernel_name, "kernel_ms": kernel_ms_max,
@@ -522,13 +737,17 @@ def main():
                          "kernel and compared with the CPU oracle applied as many times; AND over ranks"
                          % (args.verify_sample, args.warmup + args.steps),
     }
-    if kernel_name == "k_perm_fast":
-        eq = (OPS64_PER_PERM + 0.5 * OPS32_PER_PERM) * n / (kernel_ms_max * 1e-3) / 64 / 1e9
+    if prof and prof.get("valu_instructions_per_wave"):
+        # instructions per wave (= per 64 permutations... per lane: per permutation) from the counters of the keyed record
+        ops32 = float(prof["valu_instructions_per_wave"]) - OPS64_PER_PERM
+        eq = (OPS64_PER_PERM + 0.5 * ops32) * n / (kernel_ms_max * 1e-3) / 64 / 1e9
         out["valu_issue"] = {
-            "bound": "VALU issue: 64-bit integer multiply-add pipe (the binding bound; HBM idles at 1.7 %)",
+            "bound": "VALU issue: 64-bit integer multiply-add pipe (the binding bound; HBM idles at 1.8 %)",
             "achieved": eq, "unit": "G 64-bit-equivalent wave-instr/s",
             "peak": VALU_IDEAL_G_WI, "frac": eq / VALU_IDEAL_G_WI,
-            "mads_per_perm": MADS_PER_PERM, "ops64_per_perm": OPS64_PER_PERM, "ops32_per_perm": OPS32_PER_PERM,
+            "valu_instructions_per_wave": prof["valu_instructions_per_wave"],
+            "instructions_source": "SQ_INSTS_VALU / SQ_WAVES of the same keyed record as roofline.traffic",
+            "mads_per_perm": MADS_PER_PERM, "ops64_per_perm": OPS64_PER_PERM, "ops32_per_perm": ops32,
             "note": "achieved = (64-bit ops + 0.5 x 32-bit ops) per permutation x permutations/s / 64 lanes; peak = 1024 "
                     "SIMDs x 2.4 GHz / 4 cycles (ideal pipe at the peak clock); only fewer instructions can make the "
                     "kernel faster (DESIGN.md section 5)"}
@@ -538,30 +757,45 @@ def main():
         cb, ok = cpu_baseline_and_check(H, torch, device, args.cpu_sample, timed_kernel)
         out["cpu_baseline"] = cb
         out["parity_vs_cpu_sample"] = all_ok = all_ok and ok
+    wrong = []
     if not args.no_secondary:
-        sec = {}
+        sec = dict(multi)
         try:
             sec["merkle_2p24"], leaves = merkle_record(H, torch, device, 24)
             del leaves
             torch.cuda.empty_cache()
+            attach_traffic(sec["merkle_2p24"]["roofline"], sec_prof, "merkle_2p24_tree", MERKLE_BYTES_PER_NODE * sec["merkle_2p24"]["nodes"])
             sec["single_perm"] = single_perm_record(H, torch, device)
+            if "cpu_baseline" in out:
+                sec["crossover"] = crossover_record(H, out["cpu_baseline"])
             sec["sponge_chain"] = sponge_chain_record(H, torch, device)
             sec["wire_format"] = wire_format_record(H, torch, device)
+            for k in ("to_bytes", "from_bytes"):
+                attach_traffic(sec["wire_format"][k]["roofline"], sec_prof, "wire_" + k, 64.0 * (1 << 26))
             torch.cuda.empty_cache()
             sec["gadget_witness"] = gadget_witness_record(H, torch, device)
+            attach_traffic(sec["gadget_witness"]["roofline"], sec_prof, "witness",
+                           sec["gadget_witness"]["roofline"]["algorithmic_bytes_per_state"] * float(1 << 20))
+            attach_traffic(sec["gadget_witness"]["trace"]["roofline"], sec_prof, "trace", 160.0 * 68 * (1 << 20))
             torch.cuda.empty_cache()
             sec["host_path"] = host_path_record(22)
         except Exception as e:                       # secondary records never take the headline down
             sec["error"] = repr(e)
         out["secondary"] = sec
-        merkle_bad = sec.get("merkle_2p24", {}).get("root_matches_golden") is False
-    else:
-        merkle_bad = False
+        # ... but a WRONG result does fail the job (after the line is out)
+        if sec.get("merkle_2p24", {}).get("root_matches_golden") is False:
+            wrong.append("the 2^24-leaf Merkle root differs from the CPU oracle's committed root")
+        ms_ = sec.get("merkle_2p24_sharded") or {}
+        if ms_.get("root_matches_golden") is False:
+            wrong.append("the SHARDED 2^24-leaf Merkle root differs from the CPU oracle's committed root")
+        c5 = sec.get("config5") or {}
+        if c5.get("parity_vs_cpu_sample") is False or c5.get("digest_matches_one_device") is False:
+            wrong.append("configs[4]: the shards differ from the oracle sample or from the one-device digest")
     print(json.dumps(out), flush=True)
     if not all_ok:
         raise SystemExit("GPU output differs from the CPU oracle")
-    if merkle_bad:                                   # ... but a WRONG tree does fail the job (after the line is out)
-        raise SystemExit("the 2^24-leaf Merkle root differs from the CPU oracle's committed root")
+    if wrong:
+        raise SystemExit("; ".join(wrong))
 
 
 def bench_merkle(args, H, torch, device, sharding, rank, world):

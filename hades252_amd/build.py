@@ -60,6 +60,18 @@ def perm_fast_hash() -> str:
     return h.hexdigest()
 
 
+def device_source_hash() -> str:
+    """Hash of everything that determines the DEVICE code of every kernel: the kernel headers, the generated tables and the
+    flags -- not the host code of hades252.hip (launch policy, pools, the C ABI), whose edits leave a kernel's traffic per
+    launch as it was.  Keys the committed counter records of the kernels other than k_perm_fast
+    (profiles/hbm_traffic.json `secondary_kernels`)."""
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in sorted(x for x in DEPS if x.endswith((".hpp", ".inc"))):
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(d.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def _fresh(want: str) -> bool:
     if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return False

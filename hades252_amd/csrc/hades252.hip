@@ -100,6 +100,17 @@ static inline bool misaligned(const void *p) { return ((uintptr_t)p & 15u) != 0;
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 static inline size_t lds_for(int nw) { return (size_t)kWavesPerBlock * lds_wave_bytes(nw); }
 static constexpr size_t kMaxLaunchRecords = (size_t)1 << 30;   // grid.x * 256 per launch
+// Records per launch of the one entry point that takes more than that and loops (hades252_perm_batch_dev_ex).  Test hook:
+// HADES252_TEST_MAX_LAUNCH (read once, at the first call) lowers it so that the loop's second and later trips run on a
+// batch of a few thousand states (tests/test_gpu_perm.py); everything else keeps rejecting n > kMaxLaunchRecords.
+static size_t max_launch_records() {
+    static const size_t v = []() -> size_t {
+        const char *e = getenv("HADES252_TEST_MAX_LAUNCH");
+        const size_t t = e ? (size_t)strtoull(e, nullptr, 0) : 0;
+        return t >= 1 && t < kMaxLaunchRecords ? t : kMaxLaunchRecords;
+    }();
+    return v;
+}
 
 static int launch_perm_fast(const uint8_t *in, uint8_t *out, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_perm_fast, dim3(blocks_for(n)), dim3(kBlock), lds_for(5), s, in, out, n);
@@ -303,8 +314,9 @@ int hades252_perm_batch_dev_ex(void *d_states, size_t n_perms, void *stream, int
     uint8_t *p = (uint8_t *)d_states;
     // small batches are latency-bound: five waves per state (hades_coop.hpp); large ones one state per lane
     if (kernel == HADES252_KERNEL_DEFAULT) kernel = kernel_for(n_perms);
-    for (size_t off = 0; off < n_perms; off += kMaxLaunchRecords) {
-        size_t n = n_perms - off < kMaxLaunchRecords ? n_perms - off : kMaxLaunchRecords;
+    const size_t cap = max_launch_records();
+    for (size_t off = 0; off < n_perms; off += cap) {
+        size_t n = n_perms - off < cap ? n_perms - off : cap;
         if (kernel == HADES252_KERNEL_LANES) {
             if (n <= kLanesHelpedMaxStates)
                 hipLaunchKernelGGL(k_perm_lanes<true>, dim3((unsigned)((n + kLanesWaves - 2) / (kLanesWaves - 1))),
@@ -539,8 +551,11 @@ static void release_pipe(HostPipe p, bool failed = false) {
     if (free_aux || free_buf || free_stage) (void)hipGetLastError();
 }
 
-// slot_bytes == 0: a small call (needs the page-locked staging buffer, no device buffer)
-static int acquire_pipe(size_t slot_bytes, HostPipe &out) {
+// slot_bytes == 0: a small call (needs the page-locked staging buffer, no device buffer).  want_stage: the call will go
+// through the staging threads -- it first looks among the pooled pipes that already own the 120 MiB page-locked staging
+// buffer (otherwise a stage-less pipe would allocate a second one while a staged pipe sits idle, and release_pipe would
+// free one of the two again: tens of milliseconds of hipHostMalloc / hipHostFree per call).
+static int acquire_pipe(size_t slot_bytes, HostPipe &out, bool want_stage = false) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     HostPipe p;
@@ -557,9 +572,14 @@ static int acquire_pipe(size_t slot_bytes, HostPipe &out) {
                 const bool bp = g_pool[best].pinned != nullptr, ip = g_pool[i].pinned != nullptr;
                 if ((ip && !bp) || (ip == bp && g_pool[i].slot_cap < g_pool[best].slot_cap)) best = i;
             } else {
-                // large call: the smallest buffer that fits, else the largest
+                // large call: (a staged pipe for a staging call, then) the smallest buffer that fits, else the largest
                 const size_t bc = g_pool[best].slot_cap, ic = g_pool[i].slot_cap;
-                if (bc >= slot_bytes ? (ic >= slot_bytes && ic < bc) : ic > bc) best = i;
+                const bool bs = want_stage && g_pool[best].stage != nullptr, is = want_stage && g_pool[i].stage != nullptr;
+                if (is != bs) {
+                    if (is) best = i;
+                } else if (bc >= slot_bytes ? (ic >= slot_bytes && ic < bc) : ic > bc) {
+                    best = i;
+                }
             }
         }
         if (best >= 0) {
@@ -831,7 +851,11 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
     const size_t chunk = n_perms < host_chunk_states(n_perms) ? n_perms : host_chunk_states(n_perms);
     const size_t n_chunks = (n_perms + chunk - 1) / chunk;
     uint8_t *h = (uint8_t *)states;
-    rc = acquire_pipe(chunk * 160, pipe);
+    // the route is decided before the pipe is taken: the staging-thread path moves kStageChunkStates per chunk whatever
+    // HADES252_HOST_CHUNK says, so its device slots are sized for that, and it wants a pipe that owns a staging buffer
+    const bool unpinned_big = host_pin_enabled() && n_perms * 160 >= ((size_t)8 << 20) && !host_range_pinned(h, n_perms * 160);
+    const bool staged = unpinned_big && n_perms > 2 * kStageChunkStates;
+    rc = acquire_pipe((staged && chunk < kStageChunkStates ? kStageChunkStates : chunk) * 160, pipe, staged);
     if (rc != HADES252_OK) return rc;
     bool registered = false;
     auto finish = [&](int code) {
@@ -847,9 +871,8 @@ static int perm_batch_host_on_current_device(uint64_t *states, size_t n_perms, b
     // drained by helper threads (perm_batch_host_staged) -- the caller's pages are never locked.  One chunk (8 .. 40 MiB):
     // page-locked in place for the duration of the call, so its two copies are true DMA; if that is refused, or below
     // 8 MiB, the runtime's own pageable copies.  HADES252_HOST_PIN=0 disables both (plain pageable copies).
-    if (host_pin_enabled() && n_perms * 160 >= ((size_t)8 << 20) && !host_range_pinned(h, n_perms * 160)) {
-        if (n_perms > 2 * kStageChunkStates) {
-            if (pipe.slot_cap < kStageChunkStates * 160) return finish(HADES252_ERR_INVALID_ARG);     // (acquire_pipe sized it)
+    if (unpinned_big) {
+        if (staged) {
             rc = pipe_ensure_stage(pipe);
             if (rc != HADES252_OK) return finish(rc);
             return finish(perm_batch_host_staged(h, n_perms, pipe, bytes_format));
@@ -1899,8 +1922,11 @@ struct HostCall {                 // releases what a one-shot host call holds, w
     // decides how the input travels: through staging threads when it is big, in ordinary memory and HADES252_HOST_PIN
     // allows; else straight from the caller's memory (DMA if page-locked, the runtime's pageable copy otherwise).
     // *chunk_bytes is clamped to a staging slot in the first case.  Call after acquire_pipe.
+    static bool will_stage(const void *h, size_t bytes) {
+        return host_pin_enabled() && bytes >= ((size_t)8 << 20) && !host_range_pinned(h, bytes);
+    }
     int plan_upload(const void *h, size_t bytes, size_t *chunk_bytes, size_t granule) {
-        if (!host_pin_enabled() || bytes < ((size_t)8 << 20) || host_range_pinned(h, bytes)) return HADES252_OK;
+        if (!will_stage(h, bytes)) return HADES252_OK;
         int rc = pipe_ensure_stage(pipe);
         if (rc != HADES252_OK) return rc;
         size_t cb = *chunk_bytes < StagedSource::slot_bytes() ? *chunk_bytes : StagedSource::slot_bytes();
@@ -1920,11 +1946,16 @@ struct HostCall {                 // releases what a one-shot host call holds, w
             have_pipe = false;
         }
         if (src) {
-            if (code == HADES252_ERR_HIP && tl_last_hip_error == 0) tl_last_hip_error = src->hip_error();
             delete src;
             src = nullptr;
         }
         return code;
+    }
+    // a staging thread failed (StagedSource::wait returned nullptr): the call fails with THAT thread's HIP error,
+    // whatever an earlier call left in the thread-local
+    int staged_failure() {
+        tl_last_hip_error = src ? src->hip_error() : (int)hipErrorUnknown;
+        return finish(HADES252_ERR_HIP);
     }
 };
 
@@ -1953,7 +1984,7 @@ static int merkle_root_host(const uint64_t *leaves, size_t n_leaves, int arity, 
     const size_t scratch = hades252_merkle_scratch_bytes(n1, arity);  // 0 unless the tree over level 1 has >= 2 levels
     const size_t head = (size_t)depth * 32 + 32;                      // padding table, root
     HostCall call;
-    rc = acquire_pipe(chunk * 32, call.pipe);
+    rc = acquire_pipe(chunk * 32, call.pipe, HostCall::will_stage(leaves, n_leaves * 32));
     if (rc != HADES252_OK) return rc;
     call.have_pipe = true;
     HostPipe &pp = call.pipe;
@@ -1978,7 +2009,7 @@ static int merkle_root_host(const uint64_t *leaves, size_t n_leaves, int arity, 
         uint8_t *d = (uint8_t *)pp.buf + (size_t)k * pp.slot_cap;
         if (c >= (size_t)kPipeSlots) TRY_CALL(call, F(F_SYNC, hipEventSynchronize(pp.k_done[k])));   // chunk c - kPipeSlots is hashed
         const uint8_t *from = call.src ? call.src->wait(c) : h + off * 32;
-        if (from == nullptr) return call.finish(HADES252_ERR_HIP);
+        if (from == nullptr) return call.staged_failure();
         TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d, from, n * 32, hipMemcpyHostToDevice, pp.s_in)));
         TRY_CALL(call, hipEventRecord(pp.in_done[k], pp.s_in));
         if (call.src) call.src->enqueued(c);
@@ -2018,7 +2049,8 @@ int hades252_sponge_hash(const uint64_t *msgs, size_t n_msgs, size_t msg_len, co
     if (chunk > n_msgs) chunk = n_msgs;
     if (chunk > kMaxLaunchRecords) chunk = kMaxLaunchRecords;
     HostCall call;
-    rc = acquire_pipe(chunk * msg_bytes > 16 ? chunk * msg_bytes : 16, call.pipe);
+    rc = acquire_pipe(chunk * msg_bytes > 16 ? chunk * msg_bytes : 16, call.pipe,
+                      msg_bytes && msg_bytes <= StagedSource::slot_bytes() && HostCall::will_stage(msgs, n_msgs * msg_bytes));
     if (rc != HADES252_OK) return rc;
     call.have_pipe = true;
     HostPipe &pp = call.pipe;
@@ -2040,7 +2072,7 @@ int hades252_sponge_hash(const uint64_t *msgs, size_t n_msgs, size_t msg_len, co
         if (c >= (size_t)kPipeSlots) TRY_CALL(call, F(F_SYNC, hipEventSynchronize(pp.out_done[k])));
         if (msg_bytes) {
             const uint8_t *from = call.src ? call.src->wait(c) : h + off * msg_bytes;
-            if (from == nullptr) return call.finish(HADES252_ERR_HIP);
+            if (from == nullptr) return call.staged_failure();
             TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d, from, n * msg_bytes, hipMemcpyHostToDevice, pp.s_in)));
         }
         TRY_CALL(call, hipEventRecord(pp.in_done[k], pp.s_in));
@@ -2124,7 +2156,7 @@ int hades252_sponge_hash_var(const uint64_t *scalars, size_t n_scalars, const ui
     const size_t pool_b = up16(n_scalars * 32 + 16), idx_b = up16(n_msgs * 8), dig_b = n_msgs * 32;
     const size_t scr_b = up16(hades252_sponge_sort_scratch_bytes(n_msgs));
     HostCall call;
-    rc = acquire_pipe(16, call.pipe);
+    rc = acquire_pipe(16, call.pipe, n_scalars && HostCall::will_stage(scalars, n_scalars * 32));
     if (rc != HADES252_OK) return rc;
     call.have_pipe = true;
     HostPipe &pp = call.pipe;
@@ -2141,7 +2173,7 @@ int hades252_sponge_hash_var(const uint64_t *scalars, size_t n_scalars, const ui
             for (size_t c = 0; c < n_chunks; c++) {
                 const size_t off = c * cbytes, n = total - off < cbytes ? total - off : cbytes;
                 const uint8_t *from = call.src->wait(c);
-                if (from == nullptr) return call.finish(HADES252_ERR_HIP);
+                if (from == nullptr) return call.staged_failure();
                 TRY_CALL(call, F(F_MEMCPY, hipMemcpyAsync(d_pool + off, from, n, hipMemcpyHostToDevice, pp.s_in)));
                 TRY_CALL(call, hipEventRecord(pp.in_done[c % kPipeSlots], pp.s_in));
                 call.src->enqueued(c);

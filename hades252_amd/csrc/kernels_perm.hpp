@@ -65,10 +65,13 @@ __device__ __forceinline__ void store_wire(uint8_t *wires, size_t n, int wire, s
     }
 }
 
-// x / 32 mod p, fully reduced, for x in (-2p - 2^232, p / 8): the step from the Rp form (value * 2^261) every true-form
+// x / 32 mod p, fully reduced, for x in (-30 p, p / 8): the step from the Rp form (value * 2^261) every true-form
 // kernel holds to the in-memory BlsScalar (value * 2^256).  Exact division Montgomery-style: p == 1 (mod 32), so with
-// m = (-x mod 32) + 32 the sum x + m p is a multiple of 32; it lies in (30 p, 64 p) and its 32nd part in (0.93 p, 2 p): ONE
-// conditional subtraction.  Nine multiply-adds (m p, limb by limb, on a 32-bit carry chain) and the 9 x 29 -> 8 x 32
+// m = (-x mod 32) + 32 in [32, 63] the sum x + m p is a multiple of 32; it lies in (2 p, 64 p) -- any x in (-32 p, p)
+// would do -- and its 32nd part in (0, 2 p): ONE conditional subtraction.  What the schedule hands it: products in
+// (-p - 2^253, 2^253); rows (Y - m p) / 2^29 with |Y| < 2^18.1 (p + 2^228) in (-p - 2^245, 2^245), with a round constant
+// in (-p, 0] appended in (-2 p - 2^245, 2^245) -- far inside the window (tests/test_fast_model.py asserts (-30 p, p / 8)
+// on every output and drives the row path to its extremes).  Nine multiply-adds (m p, limb by limb, on a 32-bit carry chain) and the 9 x 29 -> 8 x 32
 // packing shifted down by five bits -- against a 153 multiply-add constant product + finalize when the held value
 // carries a running scale.  Lazy limbs welcome (|limb| < 2^31 - 2^29).  tests/test_fast_model.py::finalize32_model.
 __device__ __forceinline__ Fr finalize32(const F29 &x) {
@@ -183,8 +186,9 @@ __global__ void __launch_bounds__(kBlock, 3) k_perm_witness(const uint8_t *__res
     const bool live = rec < n;
     F29 y[5];                                           // the state WITHOUT the coming round's constants, normalised
     {
-        // 160 bytes in against 31 104 out: the lanes fetch their own records (no LDS slab, which would cap the kernel at
-        // three waves per SIMD; its 92 VGPRs admit five)
+        // 160 bytes in against 31 104 out: the lanes fetch their own records, no LDS slab.  Residency is three waves per
+        // SIMD either way: the kernel holds 135 VGPRs (launch bounds (kBlock, 3) = at most 168; the codegen guard allows
+        // 152), and three or five waves measured the same when an earlier form of it fitted five
         Fr in[5];
 #pragma unroll
         for (int w = 0; w < 5; w++) in[w] = live ? load_word(states + rec * 160 + w * 32) : zero_word();

@@ -18,7 +18,10 @@ from . import strategy as H
 def subtree_split(n_leaves: int, world: int):
     """How a tree of n_leaves (a power of 4) splits over `world` ranks: returns
     (leaves_per_subtree, subtrees_per_rank).  world must divide the number of sub-trees at some
-    level, i.e. world = 4^k or 2 * 4^k."""
+    level, i.e. world = 4^k or 2 * 4^k (1, 2, 4, 8, 16, 32, ..): rank g owns the sub-trees
+    [g * subtrees_per_rank, (g + 1) * subtrees_per_rank) of that level, i.e. the leaves
+    [g * n_leaves / world, (g + 1) * n_leaves / world).  BASELINE configs[3] on 8 GPUs: 2^24 leaves ->
+    16 sub-trees of 2^20 leaves, two per rank."""
     if n_leaves < 4 or n_leaves & (n_leaves - 1) or (n_leaves.bit_length() - 1) % 2:
         raise ValueError("n_leaves must be a power of 4")
     if world < 1 or world & (world - 1):
@@ -51,13 +54,13 @@ def finish_from_subroots(subroots, tag_mont: int, out_idx: int = 1):
 
 def merkle4_root_sharded(leaves_shard, n_leaves_total: int, tag_mont: int, out_idx: int = 1):
     """Root of the whole tree from per-rank shards (one process per GPU, torch.distributed
-    initialised with the nccl/RCCL backend; world size 1 needs no process group)."""
+    initialised with the nccl/RCCL backend -- or gloo, whose gather travels through host memory;
+    world size 1 needs no process group).  Every rank returns the root."""
     import torch
-    import torch.distributed as dist
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    from . import sharding
+    world = sharding.world_size()
     mine = local_subroots(leaves_shard, n_leaves_total, world, tag_mont, out_idx)
     if world == 1:
         return finish_from_subroots(mine, tag_mont, out_idx)
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine)                 # world * subtrees_per_rank * 32 bytes in total
+    gathered = sharding.all_gather_tensor(mine)     # world * subtrees_per_rank * 32 bytes in total, rank order
     return finish_from_subroots(torch.cat(gathered), tag_mont, out_idx)

@@ -118,3 +118,84 @@ def combine_digests(digest4: List[int], device="cpu") -> List[int]:
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     h = [int(x) for x in t.cpu().tolist()]
     return [(h[2 * k] + (h[2 * k + 1] << 32)) & M64 for k in range(4)]
+
+
+def world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def backend_name() -> str:
+    """"nccl" (= RCCL on ROCm), "gloo", or "none" when no process group exists (world size 1)."""
+    import torch.distributed as dist
+    return str(dist.get_backend()) if dist.is_available() and dist.is_initialized() else "none"
+
+
+def all_gather_tensor(t):
+    """Every rank's copy of `t` (same shape and dtype on all ranks), in rank order, on t's device.  RCCL gathers device
+    tensors in place; gloo (the CPU tests, and the one-GPU rehearsal of the multi-rank path) gets host copies.  This is
+    the Merkle path's only exchange step: world x sub-trees-per-rank x 32 bytes."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [t]
+    if dist.get_backend() == "gloo" and t.device.type != "cpu":
+        host = t.detach().cpu().contiguous()
+        outs = [torch.empty_like(host) for _ in range(dist.get_world_size())]
+        dist.all_gather(outs, host)
+        return [o.to(t.device) for o in outs]
+    src = t.contiguous()
+    outs = [torch.empty_like(src) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, src)
+    return outs
+
+
+def gather_strings(text: str, device="cpu", width: int = 96) -> List[str]:
+    """Every rank's short ASCII string, in rank order (bookkeeping: which physical device a rank sat on)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [text]
+    raw = text.encode("ascii", "replace")[:width].ljust(width, b"\0")
+    t = torch.tensor(list(raw), dtype=torch.int64, device=_comm_device(device))
+    outs = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [bytes(int(v) for v in o.cpu().tolist()).rstrip(b"\0").decode("ascii", "replace") for o in outs]
+
+
+def device_identity(torch, index: int) -> str:
+    """What tells two physical GPUs apart: PCI address (domain:bus:device.function) and, where the runtime exposes it, the
+    device UUID.  From torch's device properties; the PCI address falls back to hipDeviceGetPCIBusId of the HIP runtime
+    this process has already loaded."""
+    parts = []
+    try:
+        p = torch.cuda.get_device_properties(index)
+        dom, bus, dev = (getattr(p, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        if bus is not None:
+            parts.append("pci %04x:%02x:%02x.0" % (int(dom or 0), int(bus), int(dev or 0)))
+        uuid = getattr(p, "uuid", None)
+        if uuid is not None:
+            parts.append("uuid %s" % uuid)
+        parts.append(str(getattr(p, "name", "")))
+    except Exception:
+        pass
+    if not any(x.startswith("pci") for x in parts):
+        try:
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+                parts.insert(0, "pci " + buf.value.decode("ascii", "replace").lower())
+        except Exception:
+            pass
+    return "; ".join(x for x in parts if x) or "unknown device %d" % index
+
+
+def distinct_devices(idents: List[str]) -> bool:
+    """True when no two ranks report the same physical device (compared by PCI address / UUID, not by name)."""
+    keys = []
+    for s in idents:
+        key = [x for x in s.split("; ") if x.startswith(("pci ", "uuid "))]
+        keys.append(tuple(key) if key else (s,))
+    return len(set(keys)) == len(keys)
+

@@ -88,7 +88,15 @@ const char *hades252_strerror(int code);
 int hades252_last_hip_error(void);
 const char *hades252_version(void);
 
-/* ---- Strategy::perm, batched (src/strategies.rs:140-157 via ScalarStrategy) -------------- */
+/* ---- Strategy::perm, batched (src/strategies.rs:140-157 via ScalarStrategy) --------------
+ * DELIBERATELY NOT EXPORTED: `hades252_perm_batch_cpu(uint64_t *, size_t, int n_threads)`, which SURVEY.md section 8(b)
+ * lists as "the C++ oracle / baseline".  The product has no CPU path at all: a caller that wants the reference's CPU
+ * behaviour keeps calling the reference's `ScalarStrategy` (that is what `HipStrategy` delegates the per-operation trait
+ * methods to), and the C port that `bench.py` times as `cpu_baseline` lives under oracle/ as
+ * test infrastructure -- linking it into this library would make every parity claim circular (the checker would ship
+ * inside the thing it checks) and would let a missing GPU go unnoticed.  Do not "fix" this by linking oracle/ in:
+ * tests/test_abi.py::test_no_cpu_fallback_in_product fails if anything under hades252_amd/, include/ or rust/ reaches
+ * it.  For ONE permutation per call the CPU is the right tool anyway -- see the crossover table in INTEGRATION.md. */
 /* In place on host memory, Montgomery limbs.  n_perms == 1 is exactly
  * `ScalarStrategy::new().perm(&mut state)` (README.md:60-61). */
 int hades252_perm_batch(uint64_t *states, size_t n_perms);
@@ -156,7 +164,9 @@ int hades252_warm_up(size_t n_perms_hint);
  * a big one-shot call gives up its arena / chunk buffers first.  hades252_trim() destroys every pooled pipe (pipes in
  * use by concurrent calls are untouched and return to the pool later); hades252_pool_bytes() is the device memory the
  * pool holds right now on all devices.  A long-lived process that shares the GPU with another allocator calls trim after
- * a burst of large calls. */
+ * a burst of large calls.  NOT counted by either figure: the page-locked HOST memory of the staging-thread path -- 120
+ * MiB per pipe that has served a big call from ordinary memory; at most two such buffers stay cached per device (plus
+ * one per call in flight) and a staging call reuses a pipe that owns one before allocating another; trim frees them. */
 int hades252_trim(void);
 size_t hades252_pool_bytes(void);
 
@@ -172,7 +182,11 @@ size_t hades252_pool_bytes(void);
  * streamcreate, eventcreate, sync, worker (the device selection of one worker thread of the _multi entry points),
  * thread (the start of a helper thread: staging copies, _multi workers; reported as hipErrorOutOfMemory).
  * NULL or "" disarms.  The environment variable HADES252_FAIL_AT holds the same spec for processes that cannot call
- * the hook (read once, at the first library call).  Disarmed cost: one relaxed load per wrapped call. */
+ * the hook (read once, when the library is loaded: a static initialiser, so the variable must be set before dlopen /
+ * process start).  Disarmed cost: one relaxed load per wrapped call.
+ * HADES252_TEST_MAX_LAUNCH (tests only; read at the first call of hades252_perm_batch_dev*) lowers the number of states
+ * one kernel launch of that entry point takes from 2^30, so that its multi-launch loop can be exercised on a few
+ * thousand states. */
 int hades252_fault_inject(const char *spec);
 
 /* ---- the callers of perm, host memory in, host memory out -------------------------------------------------

@@ -17,6 +17,7 @@ def pytest_collection_modifyitems(config, items):
     """A plain `pytest tests` on a machine without a GPU skips the GPU tier instead of erroring.
     When the GPU tier is asked for explicitly (`-m gpu`) nothing is skipped: a GPU box that cannot
     see its GPU must fail loudly, never pass vacuously."""
+    items.sort(key=_order_key)                      # stable: in-file order and the other files' order are kept
     markexpr = (config.getoption("-m") or "").replace(" ", "")
     if "gpu" in markexpr and "notgpu" not in markexpr:
         return
@@ -31,6 +32,19 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# Order of the GPU tier: the hot path first (SURVEY section 8 rows in order), so that under `pytest -x` a failure names the
+# row it belongs to and nothing runs before the parity of `perm` itself.  Files not listed keep their alphabetical place
+# after these.
+_GPU_ORDER = ["test_gpu_a01_perm.py", "test_gpu_a02_perop.py", "test_gpu_a13_fr.py", "test_gpu_f3_wire.py",
+              "test_gpu_f2_merkle.py", "test_gpu_f1_sponge.py", "test_gpu_f4_witness.py", "test_gpu_b_host.py",
+              "test_gpu_e_multigpu.py"]
+
+
+def _order_key(item):
+    name = os.path.basename(str(item.fspath))
+    return _GPU_ORDER.index(name) if name in _GPU_ORDER else len(_GPU_ORDER)
 
 
 @pytest.fixture(scope="session")
@@ -53,3 +67,17 @@ def kat():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="session")
+def H(hades_lib):
+    """The host-side mirror of the reference interface (ctypes over the C ABI)."""
+    from hades252_amd import strategy
+    return strategy

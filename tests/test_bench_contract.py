@@ -33,7 +33,7 @@ def test_bench_single_and_two_ranks_agree():
     # outside `value`: BASELINE configs[3] and the host-pointer boundary (native caller, PCIe-inclusive)
     mk, hp = one["secondary"]["merkle_2p24"], one["secondary"]["host_path"]
     assert mk["nodes"] == 5592405 and 0 < mk["tree_ms"] < 100 and mk["roofline"]["algorithmic_bytes_per_node"] == 160
-    assert hp["bit_exact_vs_device_path"] is True and 0 < hp["frac_of_ceiling"] < 2.0 and hp["perms"] == 1 << 22   # (> 1: a box whose bare copies run below the pipeline)
+    assert hp["bit_exact_vs_device_path"] is True and 0 < hp["frac_of_ceiling"] < 1.3 and hp["perms"] == 1 << 22   # (slightly > 1 happens: a box whose bare copies run below the pipeline; a mis-measured ceiling does not pass)
     sp = one["secondary"]["single_perm"]
     assert 20 < sp["device_us_median"] < 150 and sp["device_us_min"] <= sp["host_call_us_median"] < 400
     assert 20 < one["secondary"]["sponge_chain"]["us_per_block"] < 150
@@ -49,6 +49,14 @@ def test_bench_single_and_two_ranks_agree():
     assert one["config"]["kernel"] == "k_perm_fast" and "valu_issue" in one and "frac_of_measured" not in one["valu_issue"]
     assert one["n_gpus"] == 1 and one["parity_vs_cpu_sample"] is True
     assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1
+    # N = 1 evidence block: one rank seen, its physical device named; the crossover table of the one-call-per-permutation shape
+    assert one["dist"]["ranks_seen"] == 1 and len(one["per_gpu"]["device"]) == 1 and "pci" in one["per_gpu"]["device"][0]
+    cx = one["secondary"]["crossover"]
+    assert cx["rows"][0]["n"] == 1 and cx["gpu_beats_one_core_from_n"] is not None and cx["gpu_beats_all_cores_from_n"] is not None
+    assert cx["gpu_beats_one_core_from_n"] <= cx["gpu_beats_all_cores_from_n"] <= 4096
+    # counter-backed traffic of the secondary kernels comes from the keyed record or is null -- never a literal
+    for rl in (mk["roofline"], wf["to_bytes"]["roofline"], wf["from_bytes"]["roofline"], gw["roofline"], gw["trace"]["roofline"]):
+        assert "traffic" in rl and (rl["traffic"] is None or 0.9 < rl["traffic_over_algorithmic"] < 1.5)
     assert one["cpu_baseline"]["kind"] == "port" and one["cpu_baseline"]["cores"] >= 1
     assert one["vs_baseline"] is None and one["scaling"] == "weak" and one["config"]["workload"]
     two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",

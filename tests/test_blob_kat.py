@@ -101,7 +101,7 @@ def test_mds_blob_through_c_oracle_field_ops(oracle):
 # The reference's own constant test (src/round_constants.rs:55-65: every constant is non-zero and
 # survives to_bytes -> from_bytes), made absolute: under the loader's from_raw reading the canonical
 # bytes of ROUND_CONSTANTS[i] ARE chunk i of assets/ark.bin (and MDS_MATRIX[i][j] chunk 5i+j of
-# assets/mds.bin).  CPU twin of tests/test_gpu_round3.py::test_wire_format_pinned_to_reference_blobs.
+# assets/mds.bin).  CPU twin of tests/test_gpu_f3_wire.py::test_wire_format_pinned_to_reference_blobs.
 # ---------------------------------------------------------------------------------------------
 def blob_bytes(name):
     """The blob, regenerated with plain integers from the documented algorithm (HOWTO.md:21-39, :71-97),

@@ -110,7 +110,7 @@ def test_witness_kernel_products_stay_single_multiply_adds(device_asm):
     assert "flat_load" not in body and "scratch_" not in body
     r = res[name]
     # (three waves per SIMD: enough, measured; a couple of SGPRs parked in VGPR lanes are harmless -- the hoisted table cost 60)
-    assert r["SGPRs Spill"] <= 8 and r["VGPRs"] <= 168 and r["ScratchSize"] == 0, r
+    assert r["SGPRs Spill"] <= 8 and r["VGPRs"] <= 152 and r["ScratchSize"] == 0, r         # 135 today; 168 is where 3 waves end
 
 
 def test_perm_lanes_instruction_mix(device_asm):

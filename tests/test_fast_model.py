@@ -302,10 +302,12 @@ def test_coop_model_matches_spec_oracle():
 
 
 def finalize32_model(x):
-    """finalize32 of kernels_perm.hpp: x / 32 mod p, fully reduced, for an Rp-form value x in (-2p - 2^232, p / 8) with lazy
-    limbs: m = (-x mod 32) + 32 makes x + m p a multiple of 32 in (30 p, 64 p); one conditional subtraction."""
+    """finalize32 of kernels_perm.hpp: x / 32 mod p, fully reduced, for an Rp-form value x in (-30 p, p / 8) with lazy
+    limbs: m = (-x mod 32) + 32 makes x + m p a multiple of 32 in (2 p, 64 p); one conditional subtraction.  (Any x in
+    (-32 p, p) would do; the schedule stays inside (-2 p - 2^245, 2^253): rows reach -p - 2^245 before a round constant in
+    (-p, 0] is appended -- the bound the row path is driven to in test_finalize32_window_adversarial.)"""
     v = val(x)
-    assert -2 * P - (1 << 232) < v < (P >> 3), "finalize32: input outside its window"
+    assert -30 * P < v < (P >> 3), "finalize32: input outside its window"
     assert all(abs(l) < I31 - (1 << LB) for l in x)
     m = ((-x[0]) & 31) + 32
     out, carry = [], 0
@@ -420,17 +422,54 @@ def test_finalize32_window_adversarial():
     2^253)), rows with and without an appended constant ((-2p - eps, eps)), and the window's own edges."""
     rng = random.Random(59)
     top = (P >> 3) - 1
-    for v in [0, 1, -1, 31, -31, 32, top, top - 1, -2 * P - (1 << 232) + 1, -2 * P, -P, -P + 1, -P - 1, P >> 4] + \
+    for v in [0, 1, -1, 31, -31, 32, top, top - 1, -2 * P - (1 << 232) + 1, -2 * P, -P, -P + 1, -P - 1, P >> 4,
+              -2 * P - (1 << 246)] + \
              [rng.randrange(-2 * P, P >> 3) for _ in range(300)]:
         got = finalize32_model(D.to_balanced29_signed(v))
         assert got == v * pow(32, -1, P) % P
         if 0 <= v < (P >> 3):
             assert finalize32_model(D.to_limbs29(v)) == got                 # plain limbs, same value
+    # the window's far edge (top limb about -2^28: beyond the schedule's own values, inside the kernel's 32-bit limbs)
+    for v in (-30 * P + 1, -29 * P - 17, -17 * P + 5):
+        x = D.to_limbs29(v % (1 << (LB * (NL - 1)))) [:NL - 1] + [v >> (LB * (NL - 1))]
+        assert val(x) == v and finalize32_model(x) == v * pow(32, -1, P) % P
     # lazy limbs at the bound: a normalised value + a balanced addend
     for _ in range(50):
         a, b = rng.randrange(P >> 4), rng.randrange(P)
         x = [p + q for p, q in zip(D.to_limbs29(a), D.to_balanced29_signed(b - P))]
         assert finalize32_model(x) == (a + b - P) * pow(32, -1, P) % P
+
+
+def test_finalize32_after_rows_at_the_schedule_extremes():
+    """The row path at its worst: all five words U at the bottom of mont_lin's output range (about -p - 2^227, with and
+    without a lazy addend of about -p: the round constant seen through the map), the one-limb digit m steered to 2^29 - 1
+    (so that m p / 2^29 ~ p is subtracted), then the appended round constant at -p + 1 -- finalize32 receives about
+    -2 p - 2^245, below the window the comment used to state and inside the one that is asserted."""
+    rng = random.Random(67)
+    lo = -P - (1 << 227) + 1
+    worst = 0
+    for trial in range(60):
+        base = [lo + rng.randrange(1 << 20) for _ in range(5)]
+        if trial % 2:                                                    # words 0..3 of a partial round carry an addend
+            base = [v - P + 1 + rng.randrange(1 << 10) for v in base]
+        for j in range(5):
+            vals = list(base)
+            if j < 4:                                                    # C[j][3 - j] = 360360 / 8 is odd: steer the digit
+                k = 3 - j
+                assert D.MDS_SMALL[j][k] % 2 == 1
+                y0 = sum(D.MDS_SMALL[j][c] * vals[c] for c in range(5))
+                vals[k] += ((MASK - rng.randrange(4) - y0) * pow(D.MDS_SMALL[j][k], -1, 1 << LB)) & MASK
+            u = [D.to_balanced29_signed(v) for v in vals]
+            row = mds_row_cols(u, j, 5)
+            y = sum(D.MDS_SMALL[j][c] * vals[c] for c in range(5))
+            assert j == 4 or (y & MASK) >= MASK - 3
+            assert val(row) == (y - (y & MASK) * P) >> LB and ((y - (y & MASK) * P) & MASK) == 0
+            for c in (-P + 1, -(P >> 1), 0):
+                x = add_lazy(row, D.to_balanced29_signed(c)) if c else row
+                worst = min(worst, val(x))
+                assert finalize32_model(x) == (val(row) + c) * pow(32, -1, P) % P
+    assert worst < -2 * P - (1 << 232), "the test did not reach below the old, too tight bound"
+    assert worst > -2 * P - (1 << 247)
 
 
 def test_per_op_models_match_spec_oracle():

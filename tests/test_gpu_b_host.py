@@ -1,10 +1,12 @@
-"""GPU tier, round 4: BASELINE configs pinned to the oracle's golden roots at full size, the failure contract of the
-host-pointer entry points under injected faults, the bounded pool of pipes, the library's one dispatch rule, and the
-helped lane-split kernel under timing disturbance.  Everything goes through the C ABI."""
+"""GPU tier, SURVEY section 8 row b: the drop-in boundary on HOST memory -- `hades252_perm_batch*` (page-locked, pageable,
+staged, chunk pipeline, `_multi` workers), the one-shot Merkle / sponge host callers, device-memory helpers, graph capture,
+the failure contract under injected faults, the bounded pool, warm-up."""
+import ctypes
+import hashlib
 import json
 import os
-import sys
 import random
+import sys
 import threading
 import time
 
@@ -13,118 +15,310 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import hades_spec as S  # noqa: E402
-from oracle_lib import int_of  # noqa: E402
+import hades_spec as S  # noqa: E402,F401
+from oracle_lib import P, R, limbs_of, int_of, digest_ref  # noqa: E402,F401
+from gpu_common import *  # noqa: E402,F401,F403  (helpers shared by the GPU tier; fixtures torch_cuda / H: conftest.py)
 
 pytestmark = pytest.mark.gpu
 
-TAG4 = S.to_mont(15)
-CAP = S.to_mont(1 << 64)
+
+def test_host_entry_points(torch_cuda, hades_lib, H, oracle):
+    n = 5000
+    inp = oracle.gen_b(99, 5 * n)
+    exp = oracle.perm_batch(inp)
+    a = inp.copy()
+    H.ScalarStrategy().perm(a)                       # numpy -> hades252_perm_batch
+    assert (a == exp).all()
+    b = inp.copy()
+    assert hades_lib.hades252_perm_batch_multi(b.ctypes.data_as(ctypes.c_void_p), n, 1) == 0
+    assert (b == exp).all()
+    ndev = hades_lib.hades252_device_count()
+    assert ndev >= 1
+    c = inp.copy()
+    assert hades_lib.hades252_perm_batch_multi(c.ctypes.data_as(ctypes.c_void_p), n, 0) == 0
+    assert (c == exp).all()
+    assert hades_lib.hades252_perm_batch_multi(c.ctypes.data_as(ctypes.c_void_p), n, ndev + 1) == -1
 
 
-@pytest.fixture(scope="module")
-def torch_cuda():
-    import torch
-    assert torch.cuda.is_available(), "these tests need a GPU"
-    return torch
+def test_host_path_chunked(torch_cuda, hades_lib, H, oracle):
+    """Several chunks: exercises the event-chained copy-in / kernel / copy-out pipeline (pageable caller memory)."""
+    n = (1 << 18) * 2 + 12345
+    buf = H.gen_b(5 * n, "cuda")
+    inp = to_host(buf).copy()
+    H.ScalarStrategy().perm(buf)
+    host = inp.copy()
+    H.ScalarStrategy().perm(host)
+    assert (host == to_host(buf)).all()
 
 
-@pytest.fixture(scope="module")
-def H(hades_lib):
-    from hades252_amd import strategy
-    return strategy
+def test_host_path_concurrent_threads(torch_cuda, hades_lib, oracle):
+    """The library is re-entrant (the reference strategy is a stateless ZST): many host threads
+    permuting their own buffers at once, small and chunked sizes mixed."""
+    import threading
+    sizes = [1, 7, 300, 5000, (1 << 18) + 77, 64, 1000, 3]
+    bufs = [oracle.gen_b(1000 * i, 5 * n) for i, n in enumerate(sizes)]
+    exp = [oracle.perm_batch(b) for b in bufs]
+    rcs = [None] * len(sizes)
 
+    def work(i):
+        for _ in range(2 if sizes[i] > 10000 else 6):
+            x = bufs[i].copy()
+            rcs[i] = hades_lib.hades252_perm_batch(x.ctypes.data_as(ctypes.c_void_p), sizes[i])
+            if rcs[i] != 0 or not (x == exp[i]).all():
+                rcs[i] = -99
+                return
 
-def to_dev(torch, arr):
-    a = np.ascontiguousarray(arr, dtype=np.uint64)
-    return torch.from_numpy((a if a.flags.writeable else a.copy()).view(np.int64)).cuda()
-
-
-def to_host(t):
-    return t.cpu().numpy().view(np.uint64).reshape(-1)
-
-
-def hex_of(t):
-    return hex(int_of(to_host(t)))
-
-
-# ---------------------------------------------------------------------------------------------
-# BASELINE configs[3] at full size against the oracle's committed roots (tests/golden/kat.json, merkle4_full_size:
-# the C oracle applying src/strategies.rs:140 21 845 / 349 525 / 5 592 405 times)
-# ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("log4", [8, 10, 12])
-def test_merkle_root_equals_golden_at_full_size(torch_cuda, H, kat, log4):
-    torch = torch_cuda
-    n = 4 ** log4
-    gold = kat["merkle4_full_size"][str(n)]
-    leaves = H.gen_b(n, "cuda")
-    assert hex_of(H.merkle4_root(leaves, TAG4, 1)) == gold["root"]
-    # ... and the level two below the root = the 16 sub-roots of the multi-GPU decomposition:
-    # every sub-tree on its own, then the built tree's own copy of that level
-    q = n // 16
-    subs = [hex_of(H.merkle4_root(leaves[i * q:(i + 1) * q], TAG4, 1)) for i in range(16)]
-    assert subs == gold["sub_roots_16"]
-    if log4 <= 10:
-        tree = H.merkle_build(leaves, 4, TAG4, 1)
-        flat = to_host(tree)
-        lvl = flat[-(16 + 4 + 1) * 4:-(4 + 1) * 4]
-        assert [hex(int_of(lvl[4 * i:4 * i + 4])) for i in range(16)] == gold["sub_roots_16"]
-        assert hex(int_of(flat[-4:])) == gold["root"]
-
-
-def test_host_and_sharded_roots_equal_golden(torch_cuda, H, kat, oracle):
-    """hades252_merkle_root (host memory, chunked upload) and hades252_merkle_root_multi (8 and 16 virtual workers: the
-    8-GPU decomposition on one device) on 2^20 leaves against the committed root."""
-    n = 4 ** 10
-    gold = kat["merkle4_full_size"][str(n)]["root"]
-    leaves = oracle.gen_b(0, n)
-    assert hex(int_of(H.merkle_root_host(leaves, 4, TAG4, 1))) == gold
-    for w in (8, 16, 3):
-        assert hex(int_of(H.merkle_root_multi(leaves, 4, TAG4, 1, n_workers=w, virtual=True))) == gold
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(sizes))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert rcs == [0] * len(sizes)
 
 
 # ---------------------------------------------------------------------------------------------
-# one dispatch rule, exported
+# the drop-in boundary: page-locked host buffers, the three-stream chunk pipeline, many workers on one device
 # ---------------------------------------------------------------------------------------------
-def test_dispatch_rule_is_exported_and_consistent(torch_cuda, H, hades_lib, oracle):
-    from hades252_amd import _lib
-    names = {_lib.KERNEL_LITERAL: "k_states_literal", _lib.KERNEL_FAST: "k_perm_fast", _lib.KERNEL_COOP: "k_perm_coop",
-             _lib.KERNEL_LANES: "k_perm_lanes", _lib.KERNEL_ROWS: "k_perm_rows"}
-    for k, nm in names.items():
-        assert H.kernel_name(k, 12345) == nm
-    assert hades_lib.hades252_kernel_name(99, 1) is None
-    assert H.kernel_for(1) == _lib.KERNEL_LANES and H.kernel_for(1 << 26) == _lib.KERNEL_FAST
-    # monotone: the selector sequence over growing n never returns to an earlier form
-    order, last = [], None
-    for n in [1, 2, 700, 768, 769, 1024, 1025, 4096, 4097, 8192, 16384, 16385, 32768, 65536, 65537, 1 << 20]:
-        k = H.kernel_for(n)
-        assert k in names and k != _lib.KERNEL_LITERAL
-        assert H.kernel_name(0, n) == names[k] and H.chain_form_for(n) in names
-        if k != last:
-            order.append(k)
-            last = k
-    assert len(order) == len(set(order)) and order[0] == _lib.KERNEL_LANES and order[-1] == _lib.KERNEL_FAST
-    # the default dispatch and the forced selector it reports give the same bits (and the oracle's) around every switch
-    sizes = sorted({1, 768, 769, 1024, 1025, 4096, 4097, 16384, 16385, 20000})
-    for n in sizes:
-        inp = oracle.gen_b(31 * n, 5 * n)
-        a, b = to_dev(torch_cuda, inp), to_dev(torch_cuda, inp)
-        H.ScalarStrategy().perm(a)
-        H.ScalarStrategy(H.kernel_for(n)).perm(b)
+def test_host_alloc_register_roundtrip(torch_cuda, hades_lib, H, oracle):
+    n = 3 * (1 << 16) + 777                                  # several chunks + a ragged tail
+    inp = oracle.gen_b(5 * 9000, 5 * n)
+    exp = oracle.perm_batch(inp)
+    # (a) memory allocated by the library
+    with H.HostBuffer(n) as hb:
+        assert H.host_is_pinned(hb.array)
+        hb.array[:] = inp
+        H.ScalarStrategy().perm(hb.array)
+        assert (hb.array == exp).all()
+        # a sub-range of a pinned buffer is pinned too (what a worker of perm_multi gets)
+        assert hades_lib.hades252_host_is_pinned(ctypes.c_void_p(hb.ptr.value + 160 * 5), 160 * 100) == 1
+        assert hades_lib.hades252_host_unregister(hb.ptr) == -1       # not a registered range
+    # (b) the caller's own allocation, registered once, used for several calls
+    mine = inp.copy()
+    assert not H.host_is_pinned(mine)
+    H.host_register(mine)
+    assert H.host_is_pinned(mine)
+    H.ScalarStrategy().perm(mine)
+    assert (mine == exp).all()
+    mine[:] = inp
+    H.ScalarStrategy().perm(mine)
+    assert (mine == exp).all()
+    assert hades_lib.hades252_host_free(mine.ctypes.data_as(ctypes.c_void_p)) == -1   # not from host_alloc
+    H.host_unregister(mine)
+    assert not H.host_is_pinned(mine)
+    assert hades_lib.hades252_host_unregister(mine.ctypes.data_as(ctypes.c_void_p)) == -1   # already gone
+    # (c) pageable memory, per-call registration refused / disabled: same bits
+    plain = inp.copy()
+    H.ScalarStrategy().perm(plain)
+    assert (plain == exp).all()
+    # argument errors
+    assert hades_lib.hades252_host_alloc(None, 100) == -1
+    out = ctypes.c_void_p()
+    assert hades_lib.hades252_host_alloc(ctypes.byref(out), 0) == -1
+    assert hades_lib.hades252_host_register(None, 10) == -1
+    assert hades_lib.hades252_host_free(None) == 0 and hades_lib.hades252_host_unregister(None) == 0
+
+
+@pytest.mark.parametrize("n_chunks", [2, 3, 6, 7, 13])
+def test_host_pipeline_slot_reuse(torch_cuda, H, oracle, monkeypatch, n_chunks):
+    """Chunk counts around the number of pipeline slots (6): every slot-reuse pattern, ragged last chunk."""
+    n = (n_chunks - 1) * (1 << 16) + 4321
+    inp = oracle.gen_b(12345, 5 * n)
+    exp = oracle.perm_batch(inp)
+    with H.HostBuffer(n) as hb:
+        hb.array[:] = inp
+        H.ScalarStrategy().perm(hb.array)
+        assert (hb.array == exp).all()
+
+
+def test_host_bytes_format_through_pipeline(torch_cuda, hades_lib, H, oracle):
+    n = 2 * (1 << 16) + 99
+    inp = oracle.gen_b(777, 5 * n)
+    exp = oracle.perm_batch(inp)
+    canon_in = to_host(H.to_bytes(to_dev(torch_cuda, inp)))
+    canon_exp = to_host(H.to_bytes(to_dev(torch_cuda, exp)))
+    buf = canon_in.copy()
+    assert hades_lib.hades252_perm_batch_bytes(buf.ctypes.data_as(ctypes.c_void_p), n) == 0
+    assert (buf == canon_exp).all()
+
+
+@pytest.mark.parametrize("workers", [2, 3, 8, 64])
+def test_multi_more_workers_than_devices(torch_cuda, hades_lib, H, oracle, workers):
+    """hades252_perm_batch_multi with worker g on device g % (visible devices): the hipSetDevice threads, the shard
+    arithmetic and the register-once path of an 8-GPU node, run on whatever this box has."""
+    for n in (70001, 1 << 17, 5):                            # not divisible by the worker count; n < workers for 8, 64
+        inp = oracle.gen_b(4242 + n, 5 * n)
         exp = oracle.perm_batch(inp)
-        assert (to_host(a) == exp).all() and (to_host(b) == exp).all(), n
+        a = inp.copy()
+        H.perm_multi(a, workers, virtual=True)               # pageable: >= 8 MiB is registered once for all workers
+        assert (a == exp).all(), (workers, n)
+    with H.HostBuffer(70001) as hb:                          # caller-pinned memory shared by all workers
+        inp = oracle.gen_b(99, 5 * 70001)
+        hb.array[:] = inp
+        H.perm_multi(hb.array, workers, virtual=True)
+        assert (hb.array == oracle.perm_batch(inp)).all()
+    ndev = hades_lib.hades252_device_count()
+    tiny = oracle.gen_b(0, 5 * 4)
+    p = tiny.ctypes.data_as(ctypes.c_void_p)
+    assert hades_lib.hades252_perm_batch_multi_ex(p, 4, ndev + 1, 0) == -1          # real devices only
+    assert hades_lib.hades252_perm_batch_multi_ex(p, 4, 65, 1) == -1                # worker cap
+    assert hades_lib.hades252_perm_batch_multi_ex(p, 4, 2, 2) == -1                 # unknown flag
+    assert hades_lib.hades252_perm_batch_multi_ex(p, 0, 2, 1) == 0
+
+
+def test_multi_workers_concurrent_with_host_calls(torch_cuda, H, oracle):
+    """Workers sharing a device while other host threads call perm: the pipe pool under contention."""
+    import threading
+    n = 1 << 17
+    inp = oracle.gen_b(31, 5 * n)
+    exp = oracle.perm_batch(inp)
+    results = {}
+
+    def run(tag, fn):
+        a = inp.copy()
+        fn(a)
+        results[tag] = bool((a == exp).all())
+
+    threads = [threading.Thread(target=run, args=("multi%d" % w, lambda a, w=w: H.perm_multi(a, w, virtual=True)))
+               for w in (2, 5)]
+    threads += [threading.Thread(target=run, args=("host%d" % i, lambda a: H.ScalarStrategy().perm(a))) for i in range(3)]
+    threads += [threading.Thread(target=run, args=("small%d" % i, lambda a: [H.ScalarStrategy().perm(a[20 * j * 200:20 * (j + 1) * 200]) for j in range(n // 200 + 1)]))
+                for i in range(1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(results.values()) and len(results) == len(threads), results
+
+
+def test_device_entry_points_are_graph_capturable(torch_cuda, H, oracle):
+    """The _dev entry points only enqueue work on the caller's stream (no allocation, no synchronisation, no host read-back),
+    so a launch-bound chain -- here a whole 4^6-leaf tree (six dependent levels), a small sponge batch and an in-place
+    permutation -- can be captured once in a hipGraph and replayed on new data."""
+    torch = torch_cuda
+    tag = TAG[4]
+    n = 4 ** 6
+    leaves = H.gen_b(n, "cuda")
+    states = H.gen_b(5 * 100, "cuda").view(100, 5, 4)
+    scratch = torch.empty(max(H._lib.lib().hades252_merkle_scratch_bytes(n, 4) // 8, 2), dtype=torch.int64, device="cuda")
+    strat = H.ScalarStrategy()
+    root_e = H.merkle_root(leaves, 4, tag, 1, scratch)                       # eager, also warms everything up
+    dig_e = H.sponge_hash(leaves[:400], 4, CAP, 1)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            root_g = H.merkle_root(leaves, 4, tag, 1, scratch)
+            dig_g = H.sponge_hash(leaves[:400], 4, CAP, 1)
+            strat.perm(states)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(root_g, root_e) and torch.equal(dig_g, dig_e)
+    # new data in the same buffers, replayed: equals the oracle
+    fresh = oracle.gen_b(4242, n)
+    leaves.copy_(to_dev(torch, fresh).view(-1, 4))
+    st0 = oracle.gen_b(777, 500)
+    states.copy_(to_dev(torch, st0).view(100, 5, 4))
+    g.replay()
+    torch.cuda.synchronize()
+    assert (to_host(root_g) == oracle.merkle_tree(fresh, 4, tag, 1)[-1]).all()
+    assert (to_host(dig_g) == oracle.sponge(fresh[: 400 * 4], 4, CAP, 1)).all()
+    assert (to_host(states) == oracle.perm_batch(st0)).all()
 
 
 # ---------------------------------------------------------------------------------------------
-# failure contract of the host-pointer entry points (include/hades252.h), under injected faults
+# the callers of perm on HOST memory, and device memory for callers without HIP bindings
 # ---------------------------------------------------------------------------------------------
-def each_state_is_input_or_output(got, inp, exp):
-    g, i, e = got.reshape(-1, 20), inp.reshape(-1, 20), exp.reshape(-1, 20)
-    is_in, is_out = (g == i).all(axis=1), (g == e).all(axis=1)
-    return bool((is_in | is_out).all()), int(is_out.sum())
+@pytest.mark.parametrize("chunk_bytes", [None, "4096", "100000"])
+def test_host_merkle_root_and_sponge(torch_cuda, H, oracle, monkeypatch, chunk_bytes):
+    """hades252_merkle_root / hades252_sponge_hash: host memory in, 32 bytes per tree / message out; chunked upload behind
+    the hashing (tiny chunks force many slot reuses and ragged last chunks).  The chunk size is latched at first use, so
+    the forced sizes run in child interpreters."""
+    import subprocess, textwrap
+    if chunk_bytes is not None:
+        code = textwrap.dedent('''
+            import os, sys
+            sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, os.path.join(%r, "oracle"))
+            import numpy as np
+            from hades252_amd import strategy as H
+            import hades_spec as S
+            import oracle_lib
+            o = oracle_lib.load()
+            tag = S.to_mont(15); cap = S.to_mont(1 << 64)
+            for arity, n in ((4, 1000), (3, 5000), (2, 777), (4, 4), (4, 5)):
+                lv = o.gen_b(n, n)
+                assert (H.merkle_root_host(lv, arity, S.to_mont(2 ** arity - 1)) == o.merkle_tree(lv, arity, S.to_mont(2 ** arity - 1), 1)[-1]).all(), (arity, n)
+            for n, ln in ((1000, 3), (50, 40), (3, 1000)):
+                m = o.gen_b(n + ln, n * ln)
+                assert (H.sponge_hash_host(m, n, ln, cap, 1).reshape(-1) == o.sponge(m, ln, cap, 1)).all(), (n, ln)
+            print("child ok")
+        ''') % (ROOT, ROOT, ROOT)
+        env = dict(os.environ, HADES252_HOST_CHUNK_BYTES=chunk_bytes)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "child ok" in r.stdout, r.stderr[-3000:]
+        return
+    for arity, n in ((4, 4 ** 8), (4, 100001), (3, 3 ** 9), (2, 2), (2, 3), (4, 4 ** 10 + 17), (2, 2 ** 20)):
+        tag = TAG[arity]
+        lv = oracle.gen_b(n + arity, n)
+        depth = H.merkle_depth(n, arity)
+        opad = oracle.merkle_empty_digests(arity, depth, S.to_mont(9), tag, 1)
+        dev = to_dev(torch_cuda, lv).view(-1, 4)
+        dpad = to_dev(torch_cuda, opad).view(depth, 4)
+        assert (H.merkle_root_host(lv, arity, tag) == to_host(H.merkle_root(dev, arity, tag, 1))).all(), (arity, n)
+        assert (H.merkle_root_host(lv, arity, tag, 3, pad=opad.reshape(depth, 4).copy()) ==
+                to_host(H.merkle_root(dev, arity, tag, 3, pad=dpad))).all(), (arity, n)
+        if n <= 100001:
+            assert (H.merkle_root_host(lv, arity, tag, 1, pad=opad.reshape(depth, 4).copy()) ==
+                    oracle.merkle_tree(lv, arity, tag, 1, opad)[-1]).all(), (arity, n)
+    for n, ln, pad in ((1, 1, 1), (5, 0, 1), (1000, 7, 0), (70000, 4, 1), (3, 3000, 1), (1 << 18, 3, 1)):
+        m = oracle.gen_b(3 * n + ln, n * ln)
+        got = H.sponge_hash_host(m, n, ln, CAP, pad)
+        if ln:
+            exp = to_host(H.sponge_hash(to_dev(torch_cuda, m).view(-1, 4), ln, CAP, pad))
+            assert (got.reshape(-1) == exp).all(), (n, ln)
+        if ln == 0:                                                           # n empty messages
+            z = np.zeros(n, dtype=np.uint64)
+            assert (got.reshape(-1) == oracle.sponge_var(np.zeros(4, dtype=np.uint64), z, z, CAP, pad)).all()
+        elif n * ln <= 300000:
+            assert (got.reshape(-1) == oracle.sponge(m, ln, CAP, pad)).all(), (n, ln)
+    # ragged messages in host memory (sorted on the device above 16 384 messages), one of them outside the pool
+    rng = random.Random(31)
+    for n in (1, 700, 5000, 40000):
+        lens = [rng.choice([0, 1, 3, 4, 5, 9, 17, 40]) for _ in range(n)]
+        pool = oracle.gen_b(n, sum(lens) + 8)
+        la = np.array(lens, dtype=np.uint64)
+        oa = (np.cumsum(la) - la).astype(np.uint64)
+        if n >= 700:
+            oa[5], la[5] = np.uint64(pool.size // 4 - 2), np.uint64(3)            # runs past the end of the pool
+        got, bad = H.sponge_hash_var_host(pool, oa, la, CAP, 1)
+        exp_l = la.copy()
+        if n >= 700:
+            exp_l[5] = 0
+        assert bad == (1 if n >= 700 else 0) and (got.reshape(-1) == oracle.sponge_var(pool, oa, exp_l, CAP, 1)).all(), n
+    with pytest.raises(Exception):
+        H.merkle_root_host(oracle.gen_b(1, 1), 4, TAG[4])                         # one leaf is not a tree
+    with pytest.raises(Exception):
+        H.merkle_root_host(oracle.gen_b(1, 8), 5, TAG[4])
 
 
-SITES_PERM = ["malloc", "hostmalloc", "hostregister", "memcpy", "streamcreate", "eventcreate", "sync"]
+def test_device_memory_helpers_without_torch_allocations(hades_lib, oracle):
+    """A caller with no HIP bindings: allocate, upload, permute on its own stream, download -- only through the library."""
+    n = 3000
+    inp = oracle.gen_b(606, 5 * n)
+    out = np.zeros_like(inp)
+    d, s = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hades_lib.hades252_dev_alloc(ctypes.byref(d), inp.nbytes) == 0 and d.value
+    assert hades_lib.hades252_stream_create(ctypes.byref(s)) == 0 and s.value
+    assert hades_lib.hades252_dev_upload(d, inp.ctypes.data_as(ctypes.c_void_p), inp.nbytes, s) == 0
+    assert hades_lib.hades252_perm_batch_dev(d, n, s) == 0
+    assert hades_lib.hades252_dev_download(out.ctypes.data_as(ctypes.c_void_p), d, out.nbytes, s) == 0
+    assert hades_lib.hades252_stream_sync(s) == 0
+    assert (out == oracle.perm_batch(inp)).all()
+    assert hades_lib.hades252_stream_destroy(s) == 0 and hades_lib.hades252_dev_free(d) == 0
+    assert hades_lib.hades252_dev_free(None) == 0 and hades_lib.hades252_stream_destroy(None) == 0
+    assert hades_lib.hades252_dev_alloc(None, 16) == -1 and hades_lib.hades252_dev_alloc(ctypes.byref(d), 0) == -1
+    assert hades_lib.hades252_dev_upload(None, inp.ctypes.data_as(ctypes.c_void_p), 16, None) == -1
+    assert hades_lib.hades252_stream_sync(None) == 0
 
 
 @pytest.mark.parametrize("n", [1, 200, 3000, 70000, 300000])
@@ -593,59 +787,3 @@ def test_pool_is_bounded_and_trim_gives_memory_back(torch_cuda, H, hades_lib, or
     # and the library works afterwards
     small = leaves[: 4 * 4 ** 8]
     assert (H.merkle_root_host(small, 4, TAG4, 1) == oracle.merkle_tree(small, 4, TAG4, 1)[-1]).all()
-
-
-# ---------------------------------------------------------------------------------------------
-# the helped lane-split form under timing disturbance (the exchange is double-buffered by round parity, so
-# correctness no longer depends on the peer finishing its read within one S-box)
-# ---------------------------------------------------------------------------------------------
-def test_lanes_helped_form_is_timing_independent(torch_cuda, H, oracle):
-    torch = torch_cuda
-    from hades252_amd import _lib
-    big = H.gen_b(5 << 20, "cuda")
-    side = torch.cuda.Stream()
-    n = 768                                                       # helped form, one block per CU
-    inp = oracle.gen_b(4040, 5 * n)
-    exp = oracle.perm_batch(inp)
-    bufs = [to_dev(torch, inp) for _ in range(40)]
-    torch.cuda.synchronize()
-    with torch.cuda.stream(side):                                 # a throughput kernel hogging every SIMD beside them
-        for _ in range(3):
-            H.ScalarStrategy(_lib.KERNEL_FAST).perm(big)
-    for b in bufs:
-        H.ScalarStrategy(_lib.KERNEL_LANES).perm(b)
-    torch.cuda.synchronize()
-    for b in bufs:
-        assert (to_host(b) == exp).all()
-    # chains in the helped form (sponge: 30 dependent permutations per message) beside the same disturbance
-    msgs = oracle.gen_b(77, 500 * 119)
-    dexp = oracle.sponge(msgs, 119, CAP, 1)
-    dm = to_dev(torch, msgs).view(-1, 4)
-    with torch.cuda.stream(side):
-        H.ScalarStrategy(_lib.KERNEL_FAST).perm(big)
-    got = [H.sponge_hash(dm, 119, CAP, 1) for _ in range(4)]
-    torch.cuda.synchronize()
-    for g in got:
-        assert (to_host(g) == dexp).all()
-
-
-def test_empty_digests_is_graph_capturable(torch_cuda, H, oracle):
-    """hades252_merkle_empty_digests_dev takes e0 by value: captured once, replayed after the caller's host
-    array is long gone."""
-    torch = torch_cuda
-    e0 = S.to_mont(123456789)
-    exp = oracle.merkle_empty_digests(3, 7, e0, S.to_mont(7), 1)
-    eager = H.merkle_empty_digests(3, 7, e0, S.to_mont(7), 1)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        with torch.cuda.graph(g, stream=side):
-            pad = H.merkle_empty_digests(3, 7, e0, S.to_mont(7), 1)
-    junk = [np.random.randint(0, 2 ** 62, size=1 << 16) for _ in range(8)]       # recycle host memory
-    pad.zero_()
-    g.replay()
-    torch.cuda.synchronize()
-    del junk
-    assert torch.equal(pad, eager)
-    assert (to_host(pad) == exp.reshape(-1)).all()

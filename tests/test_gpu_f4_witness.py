@@ -1,0 +1,121 @@
+"""GPU tier, SURVEY section 8 row f4: every gate output of the reference's `GadgetStrategy` (972 wires per state,
+src/strategies/gadget.rs:41-133) against the oracle and against the gates themselves."""
+import ctypes
+import hashlib
+import json
+import os
+import random
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import hades_spec as S  # noqa: E402,F401
+from oracle_lib import P, R, limbs_of, int_of, digest_ref  # noqa: E402,F401
+from gpu_common import *  # noqa: E402,F401,F403  (helpers shared by the GPU tier; fixtures torch_cuda / H: conftest.py)
+
+pytestmark = pytest.mark.gpu
+
+
+def test_perm_witness_all_gadget_wires(torch_cuda, H, oracle):
+    """hades252_perm_witness_dev: all 972 gate outputs of the reference's GadgetStrategy per state
+    (src/strategies/gadget.rs:41-133) vs the spec oracle's restatement of that schedule, on edge and random
+    states; then batch-wide identities on 5 000 states: r2 of the last round == perm output, and every S-box
+    triple satisfies v4 == v2^2 through the device field ops."""
+    torch = torch_cuda
+    rng = random.Random(17)
+    cases = [[5000] * 5, [0] * 5, [P - 1] * 5, [1, 2, 3, 4, 5]] + [[rng.randrange(P) for _ in range(5)] for _ in range(6)]
+    n_pad = 70                                  # more than one wave, ragged
+    vals = cases + [[rng.randrange(P) for _ in range(5)] for _ in range(n_pad - len(cases))]
+    inp = np.array([l for st in vals for v in st for l in limbs_of(S.to_mont(v))], dtype=np.uint64)
+    dev = to_dev(torch, inp)
+    wires = H.perm_witness(dev)
+    assert tuple(wires.shape) == (972, n_pad, 4)
+    assert (to_host(dev) == inp).all()                       # input untouched
+    host = wires.cpu().numpy().view(np.uint64).reshape(972, n_pad, 4)
+    for i in list(range(len(cases))) + [63, 64, 69]:
+        spec = []
+        S.perm_gadget(vals[i], spec)
+        got = [int_of(host[g, i]) for g in range(972)]
+        bad = [g for g in range(972) if got[g] != S.to_mont(spec[g])]
+        assert not bad, (i, bad[:8])
+    # batch-wide identities
+    n = 5000
+    st = H.gen_b(5 * n, "cuda")
+    w = H.perm_witness(st)
+    out = st.clone()
+    H.ScalarStrategy().perm(out)
+    last = torch.stack([w[962 + 2 * j + 1] for j in range(5)], dim=1)       # r2[j] of round 66
+    assert torch.equal(last.reshape(-1), out.reshape(-1))
+    for g in (5, 8, 17, 20 + 10, 5 + 15 + 10 + 15 + 10):                    # some v2 wires (rounds 0, 0, 0, 1, 2)
+        v2, v4 = w[g].contiguous(), w[g + 1].contiguous()
+        assert torch.equal(H.fr_op(H.FR_SQUARE, v2), v4)
+
+
+def test_witness_rows_equal_trace_plus_next_round_key(torch_cuda, H, oracle):
+    """Two independent kernels at scale: for every round r and word j, the gadget's row wire r2[r][j] must equal the
+    per-round trace state + the NEXT round's constant (src/strategies/gadget.rs:102-129), on 2^14 states."""
+    torch = torch_cuda
+    n = 1 << 14
+    st = H.gen_b(5 * n, "cuda", first_elem=12345)
+    wires = H.perm_witness(st)
+    trace = H.perm_trace(st)                                   # [67, n, 5, 4]
+    base = 5                                                   # wires of round 0's key additions
+    for r in range(67):
+        full = r < 4 or r >= 63
+        base += 15 if full else 3                              # S-box wires of this round
+        for j in range(5):
+            row = wires[base + 2 * j + 1]
+            state = trace[r, :, j, :].contiguous()
+            if r < 66:
+                c = scalars_dev(torch, [oracle.round_constant(5 * (r + 1) + j)]).expand(n, 4).contiguous()
+                state = H.fr_op(H.FR_ADD, state, c)
+            assert torch.equal(row, state), (r, j)
+        base += 10
+    assert base == 972
+
+
+def test_witness_every_gate_identity_at_scale(torch_cuda, H, oracle):
+    """All 972 wires of 4 096 states against the GATES themselves (src/strategies/gadget.rs:59-69, :102-129), evaluated by
+    the device field ops on the kernel's own outputs: every S-box triple (v2 = v v, v4 = v2 v2, v5 = v4 v with v the wire
+    that feeds it), every r1 = M[j][0] z0 + M[j][1] z1 + M[j][2] z2 and r2 = r1 + M[j][3] z3 + M[j][4] z4 + c.  Together
+    with the first five wires (input + round key) this pins every wire to the input by induction."""
+    torch = torch_cuda
+    n = 1 << 12
+    st = H.gen_b(5 * n, "cuda", first_elem=99)
+    w = H.perm_witness(st)
+    mul = lambda a, b: H.fr_op(H.FR_MUL, a.contiguous(), b.contiguous())
+    add = lambda a, b: H.fr_op(H.FR_ADD, a.contiguous(), b.contiguous())
+    const = lambda v: scalars_dev(torch, [S.to_mont(v)]).expand(n, 4).contiguous()   # v: canonical integer
+    mds = [[const(v) for v in row] for row in S.mds_matrix()]
+    ark = S.round_constants()
+    state = []
+    for j in range(5):                                                          # wires 0..4: input + first round key
+        state.append(w[j])
+        assert torch.equal(w[j], add(st.view(n, 5, 4)[:, j, :], const(ark[j]))), j
+    g = 5
+    for r in range(67):
+        full = r < 4 or r >= 63
+        z = list(state)
+        for word in (range(5) if full else (4,)):
+            v = state[word]
+            assert torch.equal(w[g], mul(v, v)) and torch.equal(w[g + 1], mul(w[g], w[g])), (r, word)
+            assert torch.equal(w[g + 2], mul(w[g + 1], v)), (r, word)
+            z[word] = w[g + 2]
+            g += 3
+        nxt = []
+        for j in range(5):
+            r1 = add(add(mul(mds[j][0], z[0]), mul(mds[j][1], z[1])), mul(mds[j][2], z[2]))
+            assert torch.equal(w[g], r1), (r, j)
+            r2 = add(add(mul(mds[j][3], z[3]), mul(mds[j][4], z[4])), w[g])
+            if r < 66:
+                r2 = add(r2, const(ark[5 * (r + 1) + j]))
+            assert torch.equal(w[g + 1], r2), (r, j)
+            nxt.append(w[g + 1])
+            g += 2
+        state = nxt
+    assert g == 972

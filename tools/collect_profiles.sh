@@ -11,8 +11,8 @@ P=profiles/$TAG
 mkdir -p $P
 cp $G/bench_$TAG.json $P/bench_N1.json
 cp $G/prof_$TAG/bench_trace.json $P/bench_N1_under_rocprof.json
-cp $G/prof_$TAG/hbm_traffic.json $P/hbm_traffic.json
-cp $G/prof_$TAG/hbm_traffic.json profiles/hbm_traffic.json
+# the counter record: stamped with the measured commit (refused unless HEAD's kernel sources hash to the record's key)
+python3 tools/stamp_profile.py $G/prof_$TAG/hbm_traffic.json $P
 cp $G/prof_$TAG/pmc_summary.json $P/pmc_summary.json
 cp $G/prof_$TAG/summary.txt $P/rocprofv3_bench_2p26_summary.txt
 cp $G/prof_$TAG/latency_kernel_stats.csv $P/latency_kernel_stats.csv

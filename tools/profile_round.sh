@@ -40,6 +40,10 @@ for (k, g), d in sorted(acc.items()):
           % (k[:46], g, len(d.get("SQ_WAVES", [])), w, per_wave("SQ_INSTS_VALU"), per_wave("SQ_INSTS_SALU"), per_wave("SQ_INSTS_LDS")))
 PY
 cat $OUT/latency_kernel_instructions.txt
+# the kernels behind bench.py's secondary rooflines, at bench.py's sizes: timings plain, HBM bytes in two more passes
+python3 tools/secondary_kernels.py > $OUT/secondary_kernels.json 2> $OUT/secondary_kernels.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_sec_fetch -- python3 tools/secondary_kernels.py > /dev/null 2> $OUT/pmc_sec_fetch.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_sec_write -- python3 tools/secondary_kernels.py > /dev/null 2> $OUT/pmc_sec_write.log
 python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # wire-format kernels beyond the Infinity Cache, with HBM byte counters

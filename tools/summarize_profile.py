@@ -49,6 +49,50 @@ def pmc(dirname):
     return acc
 
 
+def secondary_kernels(build):
+    """HBM bytes of the kernels behind bench.py's `secondary` rooflines (tools/secondary_kernels.py under --pmc FETCH_SIZE
+    and --pmc WRITE_SIZE, separate passes: pmc_sec_fetch / pmc_sec_write), per launch -- per TREE for the Merkle build
+    (the sum over all of a tree's launches) -- corrected like the headline kernel's.  Keyed by build.device_source_hash()."""
+    def rows(d):
+        for f in find(d + "/**/*counter_collection.csv"):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    yield r.get("Kernel_Name", ""), r.get("Counter_Name", ""), float(r.get("Counter_Value", 0))
+    try:
+        counts = json.loads(open(os.path.join(out, "secondary_kernels.json")).read().strip().splitlines()[-1])
+    except Exception:
+        return None
+    trees = counts["merkle_2p24"]["trees_built"]
+    groups = {"wire_to_bytes": lambda k: "k_wire<0>" in k, "wire_from_bytes": lambda k: "k_wire<1>" in k,
+              "witness": lambda k: "k_perm_witness" in k, "trace": lambda k: "k_perm_trace_fast" in k,
+              "merkle_2p24_tree": lambda k: "merkle" in k}
+    acc = {g: {"FETCH_SIZE": [], "WRITE_SIZE": []} for g in groups}
+    for d in ("pmc_sec_fetch", "pmc_sec_write"):
+        for k, c, v in rows(d):
+            for g, pred in groups.items():
+                if pred(k) and c in acc[g]:
+                    acc[g][c].append(v)
+    res = {"device_source_hash": build.device_source_hash(),
+           "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes around `python3 "
+                     "tools/secondary_kernels.py` (bench.py's own record functions at bench.py's sizes); bytes = counter*1024, "
+                     "FETCH_SIZE doubled (gfx950 wide-read correction); per launch, the Merkle entry per tree build (sum "
+                     "over the tree's launches)"}
+    for g, cs in acc.items():
+        if not cs["FETCH_SIZE"] or not cs["WRITE_SIZE"]:
+            continue
+        if g == "merkle_2p24_tree":
+            rd = sum(cs["FETCH_SIZE"]) / trees * 1024 * 2
+            wr = sum(cs["WRITE_SIZE"]) / trees * 1024
+            n = trees
+        else:
+            rd = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024 * 2
+            wr = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024
+            n = len(cs["FETCH_SIZE"])
+        res[g] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr, "launches_or_trees_averaged": n}
+        print("secondary %-18s read %.5g B  write %.5g B  total %.5g B  (n=%d)" % (g, rd, wr, rd + wr, n))
+    return res
+
+
 summary = {}
 print("\n== PMC (separate passes) ==")
 for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
@@ -92,6 +136,9 @@ try:
                    "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes around `python3 bench.py "
                              "--steps 5 --warmup 1 --no-cpu-baseline` (tools/profile_round.sh); bytes = counter*1024, "
                              "FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section)"}
+            sec = secondary_kernels(_hb)
+            if sec:
+                rec["secondary_kernels"] = sec
             json.dump(rec, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
             print("\nwrote hbm_traffic.json:", rec)
 except Exception as e:                     # pragma: no cover
