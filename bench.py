@@ -552,7 +552,7 @@ def crossover_record(H, cb):
     strat = H.ScalarStrategy()
     one_core = 1e6 / cb["single_thread_value"]                     # us per permutation, one thread
     all_cores = 1e6 / cb["value"]                                  # us per permutation, all threads busy
-    sizes = [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 128, 256, 512, 1024, 4096]
+    sizes = [1, 2, 3, 4, 8, 12, 16, 17, 20, 24, 32, 48, 64, 128, 256, 512, 1024, 4096]
     rows = []
     rng = np.random.default_rng(5)
     for n in sizes:

@@ -1,0 +1,16 @@
+#!/bin/bash
+# The matrix of tools/host_path_torch_probe.py: one process per configuration.  usage: bash tools/host_path_torch_probe.sh > out.txt
+cd "$(dirname "$0")/.."
+P="python3 tools/host_path_torch_probe.py"
+$P "no torch, system runtime" --no-torch
+$P "torch first (bundled runtime)"
+HSA_ENABLE_SDMA=0 $P "torch first, HSA_ENABLE_SDMA=0"
+HSA_ENABLE_SDMA=1 $P "torch first, HSA_ENABLE_SDMA=1"
+GPU_MAX_HW_QUEUES=2 $P "torch first, GPU_MAX_HW_QUEUES=2"
+GPU_MAX_HW_QUEUES=8 $P "torch first, GPU_MAX_HW_QUEUES=8"
+HSA_ENABLE_INTERRUPT=0 $P "torch first, HSA_ENABLE_INTERRUPT=0"
+AMD_DIRECT_DISPATCH=0 $P "torch first, AMD_DIRECT_DISPATCH=0"
+HIP_FORCE_DEV_KERNARG=1 $P "torch first, HIP_FORCE_DEV_KERNARG=1"
+$P "system runtime bound first, torch after" --system-runtime-first
+HSA_ENABLE_SDMA=0 $P "no torch, HSA_ENABLE_SDMA=0" --no-torch
+$P "no torch, system runtime (again)" --no-torch
