@@ -56,9 +56,8 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_PERM = 320
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak, MI355X_MICROARCH.md
-# The binding resource is VALU issue.  Per-permutation instruction counts of k_perm_fast: static ISA count
-#  = rocprofv3 SQ_INSTS_VALU / SQ_WAVES = 83 945 per wave (profiles/r4/pmc_summary.json; 88 702
-# before the constant products became linear maps).
+# The binding resource is VALU issue.  The 64-bit operations of k_perm_fast per permutation follow from its structure
+# (DESIGN.md section 4.1); the TOTAL per wave is rocprofv3's SQ_INSTS_VALU / SQ_WAVES, read from the keyed profile record.
 MADS_PER_PERM = 99 * 387 + 59 * 89 + 5 * 97 + 67 * 265       # 64-bit multiply-adds: S-boxes, K_r, FINAL_F, linear layers
 SHIFTS_PER_PERM = 17 * 297 + 9 * 59 + 10 * 5 + 45 * 67       # 64-bit arithmetic shifts, one per column: same issue class
 OPS64_PER_PERM = MADS_PER_PERM + SHIFTS_PER_PERM

@@ -12,6 +12,18 @@ Buffers
     asynchronous on the current torch stream -- zero-copy.
   * ``numpy.ndarray`` of dtype uint64 (C-contiguous): host path, synchronous, the library moves
     the data (``hades252_perm_batch``); only ``perm`` supports it.
+    RATE WARNING for this path: in a process that imported ``torch`` first, the library runs on the
+    HIP runtime PyTorch bundles (ROCm 7.0.2), which serialises the copy-in and copy-out streams of
+    the chunk pipeline -- 2^22 states take 29.6 ms (22.7 GB/s each way: the rate the system
+    runtime gives with ``HSA_ENABLE_SDMA=0``) against 15.1 ms on the system runtime (ROCm 7.2) a
+    native / Rust caller links.  No environment setting repairs it (``HSA_ENABLE_SDMA``,
+    ``GPU_MAX_HW_QUEUES``, ``HSA_ENABLE_INTERRUPT``, ``HIP_FORCE_DEV_KERNARG``: no change;
+    ``AMD_DIRECT_DISPATCH=0``: 24 ms), and the library cannot: the cause is inside that runtime
+    (profiles/r5/host_path_torch_probe.txt).  A host-only Python caller does not need torch -- use
+    this module WITHOUT importing torch (the library then binds the system runtime: 15.1 ms).
+    Binding the system runtime first and importing torch afterwards is also full speed, but puts
+    two HIP runtimes in one process: torch tensors and streams must then never be passed to the
+    device path.
 
 There is no CPU implementation behind these methods: if ``libhades252.so`` is not built or no
 GPU is usable they raise.

@@ -145,7 +145,7 @@ def test_subtree_split_against_the_committed_sub_roots():
     n = 1 << 24
     with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
         gold = json.load(f)["merkle4_full_size"][str(n)]
-    sub16 = np.concatenate([oracle_lib.limbs_of(int(h, 16)) for h in gold["sub_roots_16"]])
+    sub16 = np.array([l for h in gold["sub_roots_16"] for l in oracle_lib.limbs_of(int(h, 16))], dtype=np.uint64)
     level4 = orc.merkle4_level(sub16, tag, 1)                      # the 4 nodes one level below the root
     assert oracle_lib.int_of(orc.merkle4_level(level4, tag, 1)) == int(gold["root"], 16)
     levels = {1: None, 4: level4, 16: sub16}

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] against the ORACLE at full size: the additive digest (include/hades252.h, hades252_digest_dev; numpy
+restatement tests/oracle_lib.py::digest_ref) of perm(generator-B states 0 .. 2^30 - 1), computed by the C oracle on this
+host's CPU cores -- about 2.5 h on 6 threads -- shard by shard (the 8 shards of the 8-GPU decomposition), resumable.
+
+    nice -n 19 python tools/oracle_config5_digest.py [threads] [log2_total]   ->  gpurun_out/oracle_config5_digest.json
+
+tests/golden/kat.json `config5_2p30` holds the result: `oracle_digest` (whole range) and `oracle_shard_digests`; the
+device-derived digest recorded there since round 2 must equal it (tests/test_oracle.py::test_config5_golden_digest_is_the_oracles)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib  # noqa: E402
+
+M64 = (1 << 64) - 1
+threads = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+log_total = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+total, world, chunk = 1 << log_total, 8, 1 << 18
+out_path = os.path.join(ROOT, "gpurun_out", "oracle_config5_digest_2p%d.json" % log_total)
+os.makedirs(os.path.dirname(out_path), exist_ok=True)
+state = {"n": total, "world": world, "chunk": chunk, "next_state": 0, "shard_digests": [[0, 0, 0, 0] for _ in range(world)],
+         "seconds": 0.0, "threads": threads}
+if os.path.exists(out_path):
+    old = json.load(open(out_path))
+    if old.get("n") == total and old.get("chunk") == chunk:
+        state = old
+orc = oracle_lib.load()
+per = total // world
+t_last = time.time()
+while state["next_state"] < total:
+    b = state["next_state"]
+    n = min(chunk, total - b)
+    t0 = time.time()
+    outp = orc.perm_batch(orc.gen_b(5 * b, 5 * n), threads)
+    d = oracle_lib.digest_ref(outp, 20 * b)
+    g = b // per
+    assert (b + n - 1) // per == g, "a chunk never straddles two shards"
+    state["shard_digests"][g] = [(x + y) & M64 for x, y in zip(state["shard_digests"][g], d)]
+    state["next_state"] = b + n
+    state["seconds"] += time.time() - t0
+    if time.time() - t_last > 60 or state["next_state"] == total:
+        t_last = time.time()
+        with open(out_path + ".tmp", "w") as f:
+            json.dump(state, f)
+        os.replace(out_path + ".tmp", out_path)
+        print("%.2f %% done, %.0f s of CPU wall so far" % (100.0 * state["next_state"] / total, state["seconds"]), flush=True)
+whole = [0, 0, 0, 0]
+for sd in state["shard_digests"]:
+    whole = [(x + y) & M64 for x, y in zip(whole, sd)]
+state["digest"] = ["%016x" % x for x in whole]
+state["shard_digests_hex"] = [["%016x" % x for x in sd] for sd in state["shard_digests"]]
+with open(out_path, "w") as f:
+    json.dump(state, f, indent=1)
+print("DONE", state["digest"])
