@@ -35,8 +35,9 @@ Also in the line:
   dist          N > 1 evidence: backend, ranks_seen (= the process group's world size), the physical device every rank
                 sat on (PCI address / UUID, gathered) -- two ranks on one device fail the job unless --single-device.
                 With N > 1 every rank also takes part in two more records under `secondary`:
-                `config5` (BASELINE configs[4] at world size 8: 2^27 states per GPU, 3 timed launches, oracle samples on
-                every rank, the sum of the shard digests against the committed digest of the one-device 2^30 run) and
+                `config5_2p30` (BASELINE configs[4] at world size 8: 2^27 states per GPU, 3 timed launches, oracle samples
+                on every rank, the sum of the shard digests against the committed digest of the whole 2^30 batch;
+                `config5_rehearsal` at other world sizes: the same code on --perms-per-gpu states) and
                 `merkle_2p24_sharded` (the 2^24-leaf tree sharded by sub-tree: local sub-roots, ONE all_gather of 32-byte
                 sub-roots -- the path's only exchange step -- and the top levels; root against the oracle's committed root).
   crossover     under `secondary`: the smallest batch for which one hades252_perm_batch call beats the CPU port
@@ -442,7 +443,7 @@ def config5_record(args, H, torch, device, sharding, rank, world):
     digests after the FIRST launch against the digest of the same 2^30 outputs computed on ONE device
     (tests/golden/kat.json `config5_2p30`).  At any other world size (the one-GPU rehearsal of this path) the shard is
     --perms-per-gpu states and rank 0 computes the one-device digest itself when the whole range is small."""
-    n = (1 << 27) if world == 8 else (args.perms_per_gpu or (1 << 20))
+    n = (1 << 27) if (world == 8 and not args.single_device) else (args.perms_per_gpu or (1 << 20))
     total = n * world
     first_perm, _ = sharding.weak_shard(rank, n)
     st = torch.empty((n, 5, 4), dtype=torch.int64, device=device)
@@ -684,7 +685,9 @@ def main():
     # the records every rank takes part in (N > 1): configs[4] and the sharded tree with its one exchange step
     multi = {}
     if world > 1 and not args.no_secondary:
-        for name, fn in (("config5", lambda: config5_record(args, H, torch, device, sharding, rank, world)),
+        # (BASELINE configs[4] proper needs 8 ranks; at any other world size the same code runs at rehearsal size)
+        c5_name = "config5_2p30" if (world == 8 and not args.single_device) else "config5_rehearsal"
+        for name, fn in ((c5_name, lambda: config5_record(args, H, torch, device, sharding, rank, world)),
                          ("merkle_2p24_sharded", lambda: merkle_sharded_record(H, torch, device, sharding, rank, world))):
             try:
                 multi[name] = fn()
@@ -787,7 +790,7 @@ def main():
         ms_ = sec.get("merkle_2p24_sharded") or {}
         if ms_.get("root_matches_golden") is False:
             wrong.append("the SHARDED 2^24-leaf Merkle root differs from the CPU oracle's committed root")
-        c5 = sec.get("config5") or {}
+        c5 = sec.get("config5_2p30") or sec.get("config5_rehearsal") or {}
         if c5.get("parity_vs_cpu_sample") is False or c5.get("digest_matches_one_device") is False:
             wrong.append("configs[4]: the shards differ from the oracle sample or from the one-device digest")
     print(json.dumps(out), flush=True)

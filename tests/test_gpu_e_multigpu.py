@@ -92,7 +92,7 @@ def test_bench_two_ranks_rehearsal_prints_both_multi_rank_records(torch_cuda, ha
     assert d["backend"] == "gloo" and d["ranks_seen"] == 2 and d["single_device"] is True and d["distinct_devices"] is False
     assert len(out["per_gpu"]["device"]) == 2 and out["per_gpu"]["device"][0] == out["per_gpu"]["device"][1]
     assert "pci" in out["per_gpu"]["device"][0]
-    c5 = out["secondary"]["config5"]
+    c5 = out["secondary"]["config5_rehearsal"]
     assert c5["total_perms"] == 2 << 20 and len(c5["kernel_ms_per_rank"]) == 2 and c5["parity_vs_cpu_sample"] is True
     assert c5["digest_matches_one_device"] is True and c5["value"] > 0
     ms = out["secondary"]["merkle_2p24_sharded"]
@@ -101,6 +101,23 @@ def test_bench_two_ranks_rehearsal_prints_both_multi_rank_records(torch_cuda, ha
     assert out["secondary"]["merkle_2p24"]["root_matches_golden"] is True        # the one-device tree of the same run
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_rehearsal_2ranks.json"), "w") as f:
+        json.dump(out, f)
+
+
+def test_bench_eight_ranks_rehearsal_is_the_production_split(torch_cuda, hades_lib, kat):
+    """World size 8 -- the node BASELINE configs[4] names -- with all eight ranks on the one device of the test box, at
+    rehearsal size: the tree splits into 16 sub-trees of 2^20 leaves, two per rank, the all_gather
+    carries 16 sub-roots, every rank's device is reported, and both multi-rank records come out TRUE."""
+    out, _ = _bench(["--gpus", "8", "--single-device", "--dist-backend", "gloo", "--perms-per-gpu", "262144", "--steps", "2",
+                     "--warmup", "1", "--cpu-sample", "4096"])
+    assert out["n_gpus"] == 8 and out["dist"]["ranks_seen"] == 8 and len(out["per_gpu"]["device"]) == 8
+    assert out["parity_vs_cpu_sample"] is True and len(out["per_gpu"]["kernel_ms_per_rank"]) == 8
+    c5 = out["secondary"]["config5_rehearsal"]
+    assert c5["total_perms"] == 8 * 262144 and c5["parity_vs_cpu_sample"] is True and c5["digest_matches_one_device"] is True
+    ms = out["secondary"]["merkle_2p24_sharded"]
+    assert ms["root_matches_golden"] is True and "2 sub-tree(s) of 1048576 leaves per rank" in ms["workload"]
+    assert "16 sub-roots" in ms["workload"] and "512 bytes" in ms["exchange"]
+    with open(os.path.join(ROOT, "gpurun_out", "bench_rehearsal_8ranks.json"), "w") as f:
         json.dump(out, f)
 
 

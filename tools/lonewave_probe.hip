@@ -1,4 +1,6 @@
 // lonewave_probe.hip -- A/B of the lone-wave instantiation of the throughput kernel.
+// MEASURED AND NOT BUILT (profiles/r5/lonewave_probe.txt): the variants are a patch of hades_fast.hpp, not part of it --
+//   git apply tools/lonewave_variants.patch && <the hipcc line below> && git checkout hades252_amd/csrc/hades_fast.hpp
 //
 // Between 2^14 and 2^17 states the grid of k_perm_fast puts at most ONE wave on a SIMD (65 536 states = 1 024 waves = 1 024
 // SIMDs), and a lone wave issued one instruction per 4.97 cycles against 4.15 under saturation.
