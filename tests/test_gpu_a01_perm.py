@@ -38,6 +38,21 @@ def test_single_perm_kats(torch_cuda, hades_lib, H, kat, kernel):
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
+def test_hades_det_like_reference(torch_cuda, hades_lib, H, kernel):
+    """The reference's own test of this path, src/strategies/scalar.rs:62-74, on the device: perm([17; 5]) twice gives the
+    same state, and differs from perm([19; 5]).  (The reference pins nothing more; the known answers are in
+    test_single_perm_kats.)"""
+    torch = torch_cuda
+    def perm(start):
+        x = scalars_dev(torch, [S.to_mont(start)] * 5).view(-1)            # perm(start): BlsScalar::from(u64)
+        H.ScalarStrategy(kernel).perm(x)
+        return to_host(x)
+    x, y, z = perm(17), perm(17), perm(19)
+    assert (x == y).all() and (x != z).any()
+    assert int_of(x[:4]) == S.to_mont(S.perm([17] * 5)[0])
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1000, 4097])
 def test_ragged_batches(torch_cuda, hades_lib, H, oracle, kernel, n):
     torch = torch_cuda

@@ -79,43 +79,116 @@ def test_witness_rows_equal_trace_plus_next_round_key(torch_cuda, H, oracle):
     assert base == 972
 
 
-def test_witness_every_gate_identity_at_scale(torch_cuda, H, oracle):
-    """All 972 wires of 4 096 states against the GATES themselves (src/strategies/gadget.rs:59-69, :102-129), evaluated by
-    the device field ops on the kernel's own outputs: every S-box triple (v2 = v v, v4 = v2 v2, v5 = v4 v with v the wire
-    that feeds it), every r1 = M[j][0] z0 + M[j][1] z1 + M[j][2] z2 and r2 = r1 + M[j][3] z3 + M[j][4] z4 + c.  Together
-    with the first five wires (input + round key) this pins every wire to the input by induction."""
-    torch = torch_cuda
-    n = 1 << 12
-    st = H.gen_b(5 * n, "cuda", first_elem=99)
-    w = H.perm_witness(st)
+def gate_violations(torch, H, st, w):
+    """The gates of the reference's GadgetStrategy (src/strategies/gadget.rs:59-69, :102-129) evaluated by the device field
+    ops on a claimed witness `w` (972 wires x n scalars) for the input states `st`: returns the list of gate indices whose
+    output wire does not satisfy its gate for at least one state -- empty for a valid witness.  Every S-box triple
+    (v2 = v v, v4 = v2 v2, v5 = v4 v with v the wire that feeds it), every r1 = M[j][0] z0 + M[j][1] z1 + M[j][2] z2 and
+    r2 = r1 + M[j][3] z3 + M[j][4] z4 + c; with the first five wires (input + round key) this pins every wire to the
+    input by induction."""
+    n = st.numel() // 20
     mul = lambda a, b: H.fr_op(H.FR_MUL, a.contiguous(), b.contiguous())
     add = lambda a, b: H.fr_op(H.FR_ADD, a.contiguous(), b.contiguous())
     const = lambda v: scalars_dev(torch, [S.to_mont(v)]).expand(n, 4).contiguous()   # v: canonical integer
     mds = [[const(v) for v in row] for row in S.mds_matrix()]
     ark = S.round_constants()
+    bad = []
+
+    def gate(idx, expect):
+        if not torch.equal(w[idx], expect):
+            bad.append(idx)
+
     state = []
     for j in range(5):                                                          # wires 0..4: input + first round key
         state.append(w[j])
-        assert torch.equal(w[j], add(st.view(n, 5, 4)[:, j, :], const(ark[j]))), j
+        gate(j, add(st.view(n, 5, 4)[:, j, :], const(ark[j])))
     g = 5
     for r in range(67):
         full = r < 4 or r >= 63
         z = list(state)
         for word in (range(5) if full else (4,)):
             v = state[word]
-            assert torch.equal(w[g], mul(v, v)) and torch.equal(w[g + 1], mul(w[g], w[g])), (r, word)
-            assert torch.equal(w[g + 2], mul(w[g + 1], v)), (r, word)
+            gate(g, mul(v, v))
+            gate(g + 1, mul(w[g], w[g]))
+            gate(g + 2, mul(w[g + 1], v))
             z[word] = w[g + 2]
             g += 3
         nxt = []
         for j in range(5):
-            r1 = add(add(mul(mds[j][0], z[0]), mul(mds[j][1], z[1])), mul(mds[j][2], z[2]))
-            assert torch.equal(w[g], r1), (r, j)
+            gate(g, add(add(mul(mds[j][0], z[0]), mul(mds[j][1], z[1])), mul(mds[j][2], z[2])))
             r2 = add(add(mul(mds[j][3], z[3]), mul(mds[j][4], z[4])), w[g])
             if r < 66:
                 r2 = add(r2, const(ark[5 * (r + 1) + j]))
-            assert torch.equal(w[g + 1], r2), (r, j)
+            gate(g + 1, r2)
             nxt.append(w[g + 1])
             g += 2
         state = nxt
     assert g == 972
+    return bad
+
+
+def test_witness_every_gate_identity_at_scale(torch_cuda, H, oracle):
+    """All 972 wires of 4 096 states against the GATES themselves, evaluated by the device field ops on the kernel's own
+    outputs (gate_violations above)."""
+    torch = torch_cuda
+    n = 1 << 12
+    st = H.gen_b(5 * n, "cuda", first_elem=99)
+    w = H.perm_witness(st)
+    assert gate_violations(torch, H, st, w) == []
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own gadget tests (src/strategies/gadget.rs:207-271), read on the device: `preimage` (random input: the
+# ScalarStrategy output equals the gadget's output wires, and the witness satisfies every gate -- what prove + verify
+# establish there), `preimage_constant` (input [5000; 5]), `preimage_fails` (a wrong witness must NOT satisfy the gates)
+# ---------------------------------------------------------------------------------------------
+def _gadget_output_rows(w):
+    nw = w.shape[0]
+    return [w[nw - 10 + 2 * j + 1] for j in range(5)]          # r2 of the last round = the permutation's output words
+
+
+def test_preimage_like_reference(torch_cuda, H):
+    torch = torch_cuda
+    rng = random.Random(20240207)
+    vals = [rng.randrange(P) for _ in range(5 * 64)]                     # gadget.rs:182-195: BlsScalar::random
+    st = scalars_dev(torch, [S.to_mont(v) for v in vals]).view(-1)
+    w = H.perm_witness(st)
+    out = st.clone()
+    H.ScalarStrategy().perm(out)                                         # gadget.rs:192: ScalarStrategy::new().perm(&mut output)
+    for j, row in enumerate(_gadget_output_rows(w)):                     # gadget.rs:166-175: assert_equal on every output word
+        assert torch.equal(row, out.view(-1, 5, 4)[:, j, :]), j
+    assert gate_violations(torch, H, st, w) == []
+
+
+def test_preimage_constant_like_reference(torch_cuda, H):
+    torch = torch_cuda
+    st = scalars_dev(torch, [S.to_mont(5000)] * 5).view(-1)              # gadget.rs:230
+    w = H.perm_witness(st)
+    out = st.clone()
+    H.ScalarStrategy().perm(out)
+    assert [hex_of(r) for r in _gadget_output_rows(w)] == [hex(S.to_mont(v)) for v in S.perm([5000] * 5)]
+    for j, row in enumerate(_gadget_output_rows(w)):
+        assert torch.equal(row, out.view(-1, 5, 4)[:, j, :]), j
+    assert gate_violations(torch, H, st, w) == []
+
+
+def test_preimage_fails_like_reference(torch_cuda, H):
+    """gadget.rs:246-271: the claimed output is the permutation of a DIFFERENT input -- the circuit must not be satisfiable.
+    Here: the witness of [5000; 5] with its output rows replaced by those of [5001; 5] violates exactly the five output
+    gates; one flipped bit in one wire of one state violates that wire's gate and the gates that consume it."""
+    torch = torch_cuda
+    st = scalars_dev(torch, [S.to_mont(5000)] * 5).view(-1)
+    other = scalars_dev(torch, [S.to_mont(5001)] * 5).view(-1)
+    w, w_other = H.perm_witness(st), H.perm_witness(other)
+    nw = w.shape[0]
+    forged = w.clone()
+    for j in range(5):
+        forged[nw - 10 + 2 * j + 1] = w_other[nw - 10 + 2 * j + 1]
+    assert gate_violations(torch, H, st, forged) == [nw - 10 + 2 * j + 1 for j in range(5)]
+    n = 256
+    stn = H.gen_b(5 * n, "cuda", first_elem=7)
+    wn = H.perm_witness(stn)
+    assert gate_violations(torch, H, stn, wn) == []
+    wn[300, 17, 0] ^= 1                                                  # wire 300 of state 17: one bit
+    bad = gate_violations(torch, H, stn, wn)
+    assert 300 in bad and len(bad) <= 12, bad                           # its own gate + the few gates that consume it

@@ -48,7 +48,7 @@ import numpy as np
 page = np.ones(20 * n, dtype=np.uint64)
 pageable = med(lambda: lib.hades252_perm_batch(page.ctypes.data_as(ctypes.c_void_p), n))
 env = " ".join("%s=%s" % (k, os.environ[k]) for k in ("HSA_ENABLE_SDMA", "GPU_MAX_HW_QUEUES", "HSA_ENABLE_INTERRUPT",
-                                                       "AMD_DIRECT_DISPATCH", "HIP_FORCE_DEV_KERNARG") if k in os.environ)
+                                                       "AMD_DIRECT_DISPATCH", "HIP_FORCE_DEV_KERNARG", "HADES252_HOST_CHUNK") if k in os.environ)
 print("%-34s page-locked %7.2f ms = %5.1f GB/s each way   pageable %7.2f ms   [%s] runtimes mapped: %s"
       % (label, pinned, 160 * n / pinned / 1e6, pageable, env or "no env", ", ".join(os.path.relpath(m, "/") for m in maps)),
       flush=True)

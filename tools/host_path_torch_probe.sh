@@ -14,3 +14,12 @@ HIP_FORCE_DEV_KERNARG=1 $P "torch first, HIP_FORCE_DEV_KERNARG=1"
 $P "system runtime bound first, torch after" --system-runtime-first
 HSA_ENABLE_SDMA=0 $P "no torch, HSA_ENABLE_SDMA=0" --no-torch
 $P "no torch, system runtime (again)" --no-torch
+# chunk size of the page-locked pipeline (default n / 32 clamped to 2^16 .. 2^18 states = 10 .. 40 MiB): does the bundled
+# runtime overlap smaller copies?  (the staging-thread path, which always moves 2^16-state chunks, is FASTER than the
+# page-locked path under torch: 20.6 ms against 29.6)
+for c in 16384 32768 65536 131072 262144; do
+  HADES252_HOST_CHUNK=$c $P "torch first, HADES252_HOST_CHUNK=$c"
+done
+for c in 32768 65536 262144; do
+  HADES252_HOST_CHUNK=$c $P "no torch, HADES252_HOST_CHUNK=$c" --no-torch
+done

@@ -24,10 +24,13 @@ out_path = os.path.join(ROOT, "gpurun_out", "oracle_config5_digest_2p%d.json" % 
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 state = {"n": total, "world": world, "chunk": chunk, "next_state": 0, "shard_digests": [[0, 0, 0, 0] for _ in range(world)],
          "seconds": 0.0, "threads": threads}
-if os.path.exists(out_path):
-    old = json.load(open(out_path))
-    if old.get("n") == total and old.get("chunk") == chunk:
-        state = old
+# resume: from the output file itself, or (a GPU box does not receive gpurun_out/) from a copy of an earlier call's partial
+# result placed at tools/oracle_config5_digest.resume.json
+for cand in (out_path, os.path.join(ROOT, "tools", "oracle_config5_digest.resume.json")):
+    if os.path.exists(cand):
+        old = json.load(open(cand))
+        if old.get("n") == total and old.get("chunk") == chunk and old.get("next_state", 0) > state["next_state"]:
+            state = old
 import numpy as np  # noqa: E402
 
 
