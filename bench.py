@@ -693,6 +693,8 @@ def main():
                 multi[name] = fn()
             except ValueError as e:          # a world size the tree does not split over: the same on every rank, no collective left open
                 multi[name] = {"error": repr(e)}
+    backend_name = sharding.backend_name()
+    sharding.shutdown(device)                # the last collective: from here on rank 0 works alone
     if rank != 0:
         if not rank_ok:
             raise SystemExit("rank %d: GPU output differs from the CPU oracle" % rank)
@@ -724,7 +726,7 @@ def main():
                     "kernel_ms_per_rank": per_rank_ms,
                     "perms_per_s_per_rank": [n / (ms * 1e-3) for ms in per_rank_ms],
                     "device": devices},
-        "dist": {"backend": sharding.backend_name(), "ranks_seen": ranks_seen, "world_size_env": world,
+        "dist": {"backend": backend_name, "ranks_seen": ranks_seen, "world_size_env": world,
                  "distinct_devices": sharding.distinct_devices(devices), "single_device": bool(args.single_device),
                  "data_path_collectives": "none (bookkeeping only: barrier, max of times, AND of checks, sum of digests)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -59,6 +59,15 @@ def barrier(device=None) -> None:
             dist.barrier()
 
 
+def shutdown(device=None) -> None:
+    """Last collective of a job: a barrier, then the process group is destroyed on every rank (so that ranks which are
+    done may exit while rank 0 goes on alone, without a communicator left half-open)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        barrier(device)
+        dist.destroy_process_group()
+
+
 def reduce_max(value: float, device="cpu") -> float:
     """MAX over ranks of a python float (elapsed seconds)."""
     import torch
