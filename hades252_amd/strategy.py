@@ -18,7 +18,7 @@ Buffers
     runtime gives with ``HSA_ENABLE_SDMA=0``) against 15.1 ms on the system runtime (ROCm 7.2) a
     native / Rust caller links.  No environment setting repairs it (``HSA_ENABLE_SDMA``,
     ``GPU_MAX_HW_QUEUES``, ``HSA_ENABLE_INTERRUPT``, ``HIP_FORCE_DEV_KERNARG``: no change;
-    ``AMD_DIRECT_DISPATCH=0``: 24 ms), and the library cannot: the cause is inside that runtime
+    ``AMD_DIRECT_DISPATCH=0``: 24 ms; chunk sizes 2^14 .. 2^18 states: 27-33 ms), and the library cannot: the cause is inside that runtime
     (profiles/r5/host_path_torch_probe.txt).  A host-only Python caller does not need torch -- use
     this module WITHOUT importing torch (the library then binds the system runtime: 15.1 ms).
     Binding the system runtime first and importing torch afterwards is also full speed, but puts

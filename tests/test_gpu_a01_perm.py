@@ -427,7 +427,7 @@ def test_config5_whole_2pow30_on_one_device(torch_cuda, H, oracle, kat):
         del shard
     assert acc == ref
     # ... and the committed record bench.py checks an 8-GPU run against (tests/golden/kat.json config5_2p30)
-    assert ["%016x" % x for x in ref] == kat["config5_2p30"]["digest"]
+    assert ["%016x" % x for x in ref] == kat["config5_2p30"]["digest"] == kat["config5_2p30"]["oracle_digest"]
     _record("config5_r2.txt", "whole 2^30 perms on one device: digest %s == sum of 8 shard digests; %d sampled states "
             "bit-exact vs oracle" % (" ".join("%016x" % x for x in ref), len(idx)))
 
