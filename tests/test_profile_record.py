@@ -16,7 +16,10 @@ REC = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 
 
 def _is_git_checkout():
-    return subprocess.run(["git", "rev-parse", "--git-dir"], cwd=ROOT, capture_output=True).returncode == 0
+    try:
+        return subprocess.run(["git", "rev-parse", "--git-dir"], cwd=ROOT, capture_output=True).returncode == 0
+    except OSError:                      # no git binary at all
+        return False
 
 
 def test_record_carries_no_hand_made_key():
