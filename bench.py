@@ -10,6 +10,8 @@ width-5 permutations per GPU (BASELINE.json configs[2]; 10 GiB in place), genera
 the counter-based generator B.  With N GPUs every rank owns its own batch of the SAME size (weak
 scaling, global element indices are disjoint; `--perms-per-gpu 134217728` gives BASELINE.json
 configs[4], 2^30 over 8 GPUs); there is no data-path collective.  Rank 0 prints ONE JSON line.
+Before the warm-up every rank runs ONE untimed parity launch and compares the digest of ALL its 2^26 outputs with the CPU
+oracle's committed digest of the same states (`parity_all_outputs_first_launch`; blocks 0 .. 7 = N up to 8).
 
 Launching: under torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the environment) this process is one
 rank.  Without it, `--gpus N` with N > 1 makes this process a LAUNCHER: it spawns N rank processes
@@ -208,6 +210,19 @@ def golden_merkle_root(n_leaves: int):
         with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
             rec = json.load(f)["merkle4_full_size"].get(str(n_leaves))
         return int(rec["root"], 16) if rec else None
+    except Exception:
+        return None
+
+
+def golden_block_digest(first_perm: int, n: int):
+    """The CPU oracle's digest of ALL outputs of perm(generator-B states [first_perm, first_perm + n)) -- committed for the
+    headline blocks (n = 2^26, first_perm a multiple of it: what rank g of an N-GPU run holds after its first launch;
+    tests/golden/kat.json `headline_2p26_blocks`, tools/oracle_block_digests.py).  None for any other range."""
+    if n != 1 << 26 or first_perm % n:
+        return None
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
+            return json.load(f)["headline_2p26_blocks"]["blocks"].get(str(first_perm // n))
     except Exception:
         return None
 
@@ -659,6 +674,13 @@ def main():
     H.gen_b(5 * n, device, first_elem=5 * first_perm, out=states.view(-1, 4))
     check = ShardCheck(torch, states, first_perm, n, args.verify_sample)
 
+    # the parity launch (untimed, before the warm-up): EVERY output of this rank's block against the oracle, through the
+    # 256-bit position-dependent digest the oracle computed over the same 2^26 states (headline configuration only)
+    strat.perm(states)
+    gold_block = golden_block_digest(first_perm, n)
+    block_ok = None
+    if gold_block is not None:
+        block_ok = ["%016x" % (d & 0xFFFFFFFFFFFFFFFF) for d in H.digest(states, first_index=20 * first_perm)] == list(gold_block)
     for _ in range(args.warmup):
         strat.perm(states)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -680,8 +702,9 @@ def main():
     kernel_ms_max = sharding.reduce_max(kernel_ms, device)
     per_rank_ms = sharding.gather_floats(kernel_ms, device)
     # the timed launches themselves, checked on every rank: sampled states after warm-up + timed steps
-    rank_ok = check.after(args.warmup + args.steps)
+    rank_ok = check.after(1 + args.warmup + args.steps) and block_ok is not False
     all_ok = sharding.reduce_min_int(1 if rank_ok else 0, device) == 1
+    blocks_checked = sharding.reduce_sum_int(1 if block_ok else 0, device)
     digest = sharding.combine_digests(H.digest(states, first_index=20 * first_perm), device)
 
     del states, check
@@ -741,9 +764,14 @@ def main():
                              "(~84 k instructions per 64 x 320 B), see valu_issue and DESIGN.md"},
         "digest": ["%016x" % d for d in digest],
         "parity_vs_cpu_sample": all_ok,
-        "parity_sample": "%d states of every rank's shard, read back after the %d timed + warm-up launches of the timed "
-                         "kernel and compared with the CPU oracle applied as many times; AND over ranks"
-                         % (args.verify_sample, args.warmup + args.steps),
+        "parity_sample": "%d states of every rank's shard, read back after the %d launches (parity launch + warm-up + timed) of "
+                         "the timed kernel and compared with the CPU oracle applied as many times; AND over ranks"
+                         % (args.verify_sample, 1 + args.warmup + args.steps),
+        # all 2^26 outputs of the first launch, on every rank whose block the oracle's digests cover (blocks 0 .. 7)
+        "parity_all_outputs_first_launch": (blocks_checked == world) if blocks_checked else None,
+        "parity_all_outputs": "digest (hades252_digest_dev, global indices) of ALL outputs of each rank's first launch == the CPU "
+                              "oracle's digest of the same 2^26 states (tests/golden/kat.json headline_2p26_blocks); ranks "
+                              "covered: %d of %d; a mismatch fails the job through parity_vs_cpu_sample" % (blocks_checked, world),
     }
     if prof and prof.get("valu_instructions_per_wave"):
         # instructions per wave (= per 64 permutations... per lane: per permutation) from the counters of the keyed record

@@ -121,6 +121,22 @@ def test_bench_eight_ranks_rehearsal_is_the_production_split(torch_cuda, hades_l
         json.dump(out, f)
 
 
+def test_bench_every_output_of_every_rank_against_the_oracle_at_headline_size(torch_cuda, hades_lib, kat):
+    """The headline configuration (2^26 states per GPU) with two ranks: ALL outputs of each rank's first launch -- blocks 0
+    and 1 of the global index space -- against the CPU oracle's committed digests of the same states
+    (kat.json headline_2p26_blocks; tools/oracle_block_digests.py), not a sample.  One rank: block 0."""
+    assert all(str(g) in kat["headline_2p26_blocks"]["blocks"] for g in range(8))
+    two, _ = _bench(["--gpus", "2", "--single-device", "--dist-backend", "gloo", "--steps", "1", "--warmup", "0",
+                     "--no-secondary", "--no-cpu-baseline"])
+    assert two["config"]["perms_per_gpu"] == 1 << 26 and two["n_gpus"] == 2
+    assert two["parity_all_outputs_first_launch"] is True and "covered: 2 of 2" in two["parity_all_outputs"]
+    assert two["parity_vs_cpu_sample"] is True
+    one, _ = _bench(["--steps", "1", "--warmup", "0", "--no-secondary", "--no-cpu-baseline"])
+    assert one["parity_all_outputs_first_launch"] is True and "covered: 1 of 1" in one["parity_all_outputs"]
+    small, _ = _bench(["--steps", "1", "--warmup", "0", "--no-secondary", "--no-cpu-baseline", "--perms-per-gpu", "65536"])
+    assert small["parity_all_outputs_first_launch"] is None and small["parity_vs_cpu_sample"] is True
+
+
 def test_bench_refuses_two_ranks_on_one_device(torch_cuda, hades_lib):
     """Two ranks that land on the same physical device without --single-device: every rank exits 4 and no line is printed."""
     import subprocess

@@ -258,3 +258,20 @@ def test_config5_golden_digest_is_the_oracles(oracle, kat):
     pr = rec["oracle_probe"]
     out = oracle.perm_batch(oracle.gen_b(5 * pr["first_state"], 5 * pr["n"]))
     assert ["%016x" % x for x in oracle_lib.digest_ref(out, 20 * pr["first_state"])] == pr["digest"]
+
+
+def test_headline_block_digests_are_consistent_with_the_config5_run(oracle, kat):
+    """tests/golden/kat.json headline_2p26_blocks: the oracle's digest of ALL outputs of every 2^26-state block 0 .. 7 (what
+    rank g of an N-GPU bench run holds after its first launch; tools/oracle_block_digests.py).  Two consecutive blocks add
+    up to one 2^27 shard of the configs[4] run -- computed by a different run with a different driver loop -- and a
+    probe of block 3 is recomputed here."""
+    import oracle_lib
+    rec, c5 = kat["headline_2p26_blocks"], kat["config5_2p30"]
+    assert rec["block_states"] == 1 << 26 and sorted(rec["blocks"], key=int) == [str(g) for g in range(8)]
+    m64 = (1 << 64) - 1
+    for g in range(4):
+        pair = [(int(x, 16) + int(y, 16)) & m64 for x, y in zip(rec["blocks"][str(2 * g)], rec["blocks"][str(2 * g + 1)])]
+        assert ["%016x" % v for v in pair] == c5["oracle_shard_digests"][g], g
+    pr = rec["probe"]
+    out = oracle.perm_batch(oracle.gen_b(5 * pr["first_state"], 5 * pr["n"]))
+    assert ["%016x" % x for x in oracle_lib.digest_ref(out, 20 * pr["first_state"])] == pr["digest"]
