@@ -318,8 +318,9 @@ def test_misaligned_device_pointer_rejected(torch_cuda, hades_lib):
 
 
 # ---- BASELINE full sizes: size-independent properties ----------------------------------------
-def test_config3_2pow26_properties(torch_cuda, hades_lib, H, oracle):
-    """BASELINE config[2]: 2^26 permutations on one GPU.  The oracle cannot replay 2^26, so:
+def test_config3_2pow26_properties(torch_cuda, hades_lib, H, oracle, kat):
+    """BASELINE config[2]: 2^26 permutations on one GPU.  (0) the digest of ALL outputs equals the one the oracle computed over
+    the same 2^26 states (25 min of CPU, once: tools/oracle_block_digests.py), and, independent of that record:
     (1) a strided sample (every 2^10-th state, 65 536 states: SURVEY section 8(d) config 3) is compared bit for bit with the oracle,
     (2) the two independent device implementations agree on the digest of ALL outputs,
     (3) one call == two ragged calls (no cross-lane / cross-launch state)."""
@@ -334,6 +335,8 @@ def test_config3_2pow26_properties(torch_cuda, hades_lib, H, oracle):
     got = to_host(a.view(n, 20)[::stride].contiguous())
     assert (got == oracle.perm_batch(host_in)).all()
     d_fast = H.digest(a)
+    # (0) ALL 2^26 outputs against the oracle: its committed digest of the same states (kat.json headline_2p26_blocks, block 0)
+    assert ["%016x" % x for x in d_fast] == kat["headline_2p26_blocks"]["blocks"]["0"]
     # literal kernel on the same inputs
     H.gen_b(5 * n, "cuda", out=a.view(-1, 4))
     H.ScalarStrategy(1).perm(a)
