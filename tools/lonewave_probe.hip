@@ -9,6 +9,7 @@
 //   bit 1   the linear layer column-major: five independent row accumulators interleaved (no extra instruction)
 //   bit 2   the K_r linear map on two accumulators (odd / even limbs)
 //   bit 4   (16) PROBE ONLY, wrong results: every round reads the same table lines (no scalar-cache misses)
+//   bit 9   (512) full rounds: the S-boxes of two words statement by statement (two independent chains, no extra instruction)
 //   bit 5   (32) the lone-wave constant pipeline: K_r's columns three ahead + the next round's cache lines touched an S-box
 //           ahead (hades_fast.hpp, fast_round)
 // For every variant and batch size: microseconds per launch (median of 9, HIP events around ONE launch) and the digest
@@ -31,7 +32,7 @@ using namespace hades;
 __constant__ FastTables d_fast = {HADES_FAST_ROUND_INIT, HADES_FAST_FINAL_F, HADES_FAST_LIN_INIT, HADES_FAST_FINAL_LIN};
 
 template <int V>
-__global__ void __launch_bounds__(256, 4) k_perm_v(const uint8_t *in, uint8_t *out, size_t n) {
+__global__ void __launch_bounds__(256, 3) k_perm_v(const uint8_t *in, uint8_t *out, size_t n) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     uint8_t *slab = lds + (threadIdx.x / kWave) * lds_wave_bytes(5);
     size_t rec0 = (size_t)blockIdx.x * 256 + (threadIdx.x / kWave) * kWave;
@@ -67,8 +68,8 @@ static void launch(const uint8_t *in, uint8_t *out, size_t n) {
 typedef void (*launch_fn)(const uint8_t *, uint8_t *, size_t);
 
 int main(int argc, char **argv) {
-    const int variants[] = {0, 64, 128, 256, 192, 320, 384};
-    launch_fn fns[] = {launch<0>, launch<64>, launch<128>, launch<256>, launch<192>, launch<320>, launch<384>};
+    const int variants[] = {0, 2, 512, 514, 0, 2, 514};
+    launch_fn fns[] = {launch<0>, launch<2>, launch<512>, launch<514>, launch<0>, launch<2>, launch<514>};
     const size_t sizes[] = {(size_t)1 << 14, (size_t)3 << 13, (size_t)1 << 15, (size_t)3 << 14, (size_t)1 << 16, (size_t)3 << 15,
                             (size_t)1 << 17, (size_t)1 << 18, (size_t)1 << 20, (size_t)1 << 24};
     const size_t nmax = (size_t)1 << (argc > 1 ? atoi(argv[1]) : 24);   // argv[1]: log2 of the largest batch (PMC runs: 16)
@@ -84,12 +85,9 @@ int main(int argc, char **argv) {
         const void *fp = nullptr;
         switch (variants[vi]) {
             case 0: fp = (const void *)k_perm_v<0>; break;
-            case 64: fp = (const void *)k_perm_v<64>; break;
-            case 128: fp = (const void *)k_perm_v<128>; break;
-            case 256: fp = (const void *)k_perm_v<256>; break;
-            case 192: fp = (const void *)k_perm_v<192>; break;
-            case 320: fp = (const void *)k_perm_v<320>; break;
-            default: fp = (const void *)k_perm_v<384>; break;
+            case 2: fp = (const void *)k_perm_v<2>; break;
+            case 512: fp = (const void *)k_perm_v<512>; break;
+            default: fp = (const void *)k_perm_v<514>; break;
         }
         CHECK(hipFuncGetAttributes(&a, fp));
         printf("variant %d: %d VGPRs, %zu B scratch\n", variants[vi], a.numRegs, (size_t)a.localSizeBytes);
