@@ -102,7 +102,7 @@ def _merkle_worker(rank, world, port, n_leaves, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])          # 8 = the production split: 16 sub-trees, two per rank
 def test_merkle_root_sharded_over_gloo(world):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
