@@ -458,7 +458,7 @@ def config5_record(args, H, torch, device, sharding, rank, world):
     digests after the FIRST launch against the CPU oracle's digest of the same 2^30 outputs (tests/golden/kat.json
     `config5_2p30`; equal to the one-device digest recorded since round 2).  At any other world size (the one-GPU rehearsal of this path) the shard is
     --perms-per-gpu states and rank 0 computes the one-device digest itself when the whole range is small."""
-    n = (1 << 27) if (world == 8 and not args.single_device) else (args.perms_per_gpu or (1 << 20))
+    n = (1 << 27) if (world == 8 and (not args.single_device or args.config5_full_size)) else (args.perms_per_gpu or (1 << 20))
     total = n * world
     first_perm, _ = sharding.weak_shard(rank, n)
     st = torch.empty((n, 5, 4), dtype=torch.int64, device=device)
@@ -625,6 +625,9 @@ def main():
     # test hooks for boxes with fewer GPUs than ranks (control-flow check of the N>1 path only)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (testing)")
+    ap.add_argument("--config5-full-size", action="store_true",
+                    help="with --single-device at world size 8: run secondary.config5_2p30 at its real size (2^27 states per "
+                         "rank, 160 GiB on the one device) instead of the rehearsal size (testing)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -713,7 +716,8 @@ def main():
     multi = {}
     if world > 1 and not args.no_secondary:
         # (BASELINE configs[4] proper needs 8 ranks; at any other world size the same code runs at rehearsal size)
-        c5_name = "config5_2p30" if (world == 8 and not args.single_device) else "config5_rehearsal"
+        c5_name = ("config5_2p30" if (world == 8 and (not args.single_device or args.config5_full_size))
+                   else "config5_rehearsal")
         for name, fn in ((c5_name, lambda: config5_record(args, H, torch, device, sharding, rank, world)),
                          ("merkle_2p24_sharded", lambda: merkle_sharded_record(H, torch, device, sharding, rank, world))):
             try:

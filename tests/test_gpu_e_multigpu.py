@@ -121,6 +121,23 @@ def test_bench_eight_ranks_rehearsal_is_the_production_split(torch_cuda, hades_l
         json.dump(out, f)
 
 
+def test_bench_config5_full_size_through_the_eight_rank_path(torch_cuda, hades_lib, kat):
+    """BASELINE configs[4] through bench.py's own N = 8 code path at its REAL size -- 2^27 states per rank, all eight ranks on
+    the one device of the test box (160 GiB resident) -- the sum of the ranks' shard digests against the CPU oracle's digest of
+    all 2^30 outputs.  What an 8-GPU node will run, minus the seven other GPUs."""
+    free, _ = torch_cuda.cuda.mem_get_info()
+    if free < (200 << 30):
+        pytest.skip("needs 200 GiB of free HBM")
+    out, _ = _bench(["--gpus", "8", "--single-device", "--config5-full-size", "--dist-backend", "gloo", "--perms-per-gpu", "65536",
+                     "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    c5 = out["secondary"]["config5_2p30"]
+    assert c5["total_perms"] == 1 << 30 and c5["perms_per_gpu"] == 1 << 27 and len(c5["kernel_ms_per_rank"]) == 8
+    assert c5["digest"] == kat["config5_2p30"]["oracle_digest"]
+    assert c5["digest_matches_oracle_at_full_size"] is True and c5["parity_vs_cpu_sample"] is True
+    with open(os.path.join(ROOT, "gpurun_out", "bench_config5_full_size_8ranks_one_device.json"), "w") as f:
+        json.dump(out, f)
+
+
 def test_bench_every_output_of_every_rank_against_the_oracle_at_headline_size(torch_cuda, hades_lib, kat):
     """The headline configuration (2^26 states per GPU) with two ranks: ALL outputs of each rank's first launch -- blocks 0
     and 1 of the global index space -- against the CPU oracle's committed digests of the same states
