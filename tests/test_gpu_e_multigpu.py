@@ -125,9 +125,12 @@ def test_bench_config5_full_size_through_the_eight_rank_path(torch_cuda, hades_l
     """BASELINE configs[4] through bench.py's own N = 8 code path at its REAL size -- 2^27 states per rank, all eight ranks on
     the one device of the test box (160 GiB resident) -- the sum of the ranks' shard digests against the CPU oracle's digest of
     all 2^30 outputs.  What an 8-GPU node will run, minus the seven other GPUs."""
+    import gc
+    gc.collect()
+    torch_cuda.cuda.empty_cache()                      # what earlier tests of this process left in torch's caching allocator
     free, _ = torch_cuda.cuda.mem_get_info()
     if free < (200 << 30):
-        pytest.skip("needs 200 GiB of free HBM")
+        pytest.skip("needs 200 GiB of free HBM (%d GiB free)" % (free >> 30))
     out, _ = _bench(["--gpus", "8", "--single-device", "--config5-full-size", "--dist-backend", "gloo", "--perms-per-gpu", "65536",
                      "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
     c5 = out["secondary"]["config5_2p30"]
