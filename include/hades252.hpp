@@ -8,6 +8,11 @@
 // batched: where the reference takes `&mut [BlsScalar]` of exactly WIDTH words, these methods take
 // any whole number of WIDTH-word states and apply the operation to each, in place.
 // Header-only; link with -lhades252 (and the HIP runtime for device buffers).
+//
+// Size switch: the Rust binding (rust/src/hip.rs, MIN_GPU_STATES = 2) sends a call that carries ONE state to the
+// reference's own CPU `ScalarStrategy` (one GPU call costs ~65 us, one CPU permutation ~50 us).  This mirror has NO
+// CPU path, on purpose -- there is no reference CPU code in a C++ caller's crate to delegate to, and a CPU leg inside
+// this library would be an oracle in the product: every call here goes to the device or throws.
 #ifndef HADES252_HPP
 #define HADES252_HPP
 

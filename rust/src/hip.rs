@@ -26,11 +26,25 @@ pub(crate) fn check(rc: i32) {
     }
 }
 
+/// States per call from which the GPU wins against THIS crate's serial CPU path: one `hades252_perm_batch` call costs
+/// about 65 us whatever it carries up to 256 states, one `ScalarStrategy::perm` about 50 us on a host core (measured,
+/// INTEGRATION.md "when NOT to route"), so a single permutation -- the reference's own call shape, README.md:60-61 --
+/// stays on the CPU and two or more go to the device.  A caller with its own pool of T threads can raise it to ~1.3 T.
+pub const MIN_GPU_STATES: usize = 2;
+
 /// Batched Hades252 strategy on MI355X; stateless like `ScalarStrategy` (src/strategies/scalar.rs:11-13).
-#[derive(Default)]
 pub struct HipStrategy {
     /// 0 = the current device; n > 0 = shard host batches over the first n GPUs (no collective).
     pub devices: i32,
+    /// Calls with fewer states than this run the reference's own `ScalarStrategy::perm` per state (never slower than
+    /// not using this strategy); 0 = always the GPU.
+    pub min_gpu_states: usize,
+}
+
+impl Default for HipStrategy {
+    fn default() -> Self {
+        Self { devices: 0, min_gpu_states: MIN_GPU_STATES }
+    }
 }
 
 impl HipStrategy {
@@ -50,11 +64,15 @@ impl Strategy<BlsScalar> for HipStrategy {
     fn mul_matrix<'b, I: Iterator<Item = &'b BlsScalar>>(&mut self, constants: &mut I, values: &mut [BlsScalar]) {
         ScalarStrategy::new().mul_matrix(constants, values)
     }
-    /// Overrides the provided `perm` (src/strategies.rs:140-157): every WIDTH-sized chunk of `data` is permuted in place
-    /// by one GPU call; `data.len() == WIDTH` is exactly `ScalarStrategy::perm`.
+    /// Overrides the provided `perm` (src/strategies.rs:140-157): every WIDTH-sized chunk of `data` is permuted in place,
+    /// `min_gpu_states` or more by one GPU call, fewer by `ScalarStrategy` (bit-identical either way);
+    /// `data.len() == WIDTH` is exactly `ScalarStrategy::perm`.
     fn perm(&mut self, data: &mut [BlsScalar]) {
         assert!(data.len() % WIDTH == 0, "Hades252 state length must be a multiple of WIDTH");
         let (p, n) = (data.as_mut_ptr() as *mut u64, data.len() / WIDTH);
+        if n < self.min_gpu_states {
+            return data.chunks_mut(WIDTH).for_each(|state| ScalarStrategy::new().perm(state));
+        }
         check(unsafe { if self.devices > 0 { hades252_perm_batch_multi(p, n, self.devices) } else { hades252_perm_batch(p, n) } });
     }
 }

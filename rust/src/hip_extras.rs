@@ -157,10 +157,31 @@ mod tests {
     #[test]
     fn hip_matches_scalar() {
         let mut a = [BlsScalar::from(17u64); WIDTH];
-        let mut b = a;
+        let (mut b, mut c) = (a, a);
         ScalarStrategy::new().perm(&mut a);
-        HipStrategy::new().perm(&mut b);
+        // one state goes to the CPU by default (`MIN_GPU_STATES`); 0 forces the device
+        HipStrategy { devices: 0, min_gpu_states: 0 }.perm(&mut b);
+        HipStrategy::new().perm(&mut c);
         assert_eq!(a, b);
+        assert_eq!(a, c);
+    }
+
+    // the size switch changes where a batch runs, never its result -- on both sides of every threshold
+    #[test]
+    fn hip_size_switch_is_invisible() {
+        for n in [0usize, 1, 2, 3, 23, 24, 25] {
+            let mut expect: Vec<BlsScalar> = (0..(WIDTH * n) as u64).map(|v| BlsScalar::from(v * v + 7)).collect();
+            let (mut gpu, mut cpu, mut dflt) = (expect.clone(), expect.clone(), expect.clone());
+            for chunk in expect.chunks_mut(WIDTH) {
+                ScalarStrategy::new().perm(chunk);
+            }
+            HipStrategy { devices: 0, min_gpu_states: 0 }.perm(&mut gpu);
+            HipStrategy { devices: 0, min_gpu_states: usize::MAX }.perm(&mut cpu);
+            HipStrategy::new().perm(&mut dflt);
+            assert_eq!(gpu, expect);
+            assert_eq!(cpu, expect);
+            assert_eq!(dflt, expect);
+        }
     }
 
     #[test]
