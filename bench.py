@@ -45,6 +45,11 @@ Also in the line:
   crossover     under `secondary`: the smallest batch for which one hades252_perm_batch call beats the CPU port
                 (one core / all cores) -- the reference's own call shape is ONE permutation per call (README.md:60-61).
 `--workload merkle` times the tree build itself as the step (development; the driver runs the default).
+`--total-perms T` (strong scaling): T permutations IN ALL, rank g owns the contiguous range [g T / N, (g + 1) T / N);
+`--total-perms 1073741824` is BASELINE configs[4] at any N (one device holds all 160 GiB at N = 1), the line then says
+`"scaling": "strong"` and every rank's first launch is checked against the CPU oracle's digest of ALL 2^30 outputs.  The
+default (weak) run carries the same measurement at every N -- N = 1 included -- as `secondary.config5_2p30`, so that the
+driver's 1 / 2 / 4 / 8 runs give a strong-scaling curve for configs[4] beside the weak-scaling headline.
 """
 from __future__ import annotations
 
@@ -90,37 +95,58 @@ def usable_cores() -> int:
 
 
 def cpu_baseline_and_check(H, torch, device, n_sample: int, kernel: int):
-    """Time the CPU oracle on the first n_sample permutations of the workload and use its
-    output to check the GPU path.  The oracle is used here only as baseline + checker."""
+    """Time the CPU oracle on the first n_sample permutations of the workload and use its output to check the GPU path.
+    The oracle is used here only as baseline + checker.  Two builds of the SAME source are timed: the portable one the
+    tests check against (-march=x86-64-v3: it travels between machines) and one compiled on THIS host with -O3
+    -march=native -- `value` is the better of the two, so the baseline is never handicapped by
+    the flags; the GPU output is compared with the portable build's, and the native build's output with it too."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib
     orc = oracle_lib.load()
     cores = usable_cores()
     inp = orc.gen_b(0, 5 * n_sample)
-    # single thread on a slice sized for >= 2 s (calibrated on 2 048 permutations), all cores on the whole sample
-    t0 = time.perf_counter()
-    orc.perm_batch(inp[:20 * 2048], 1)
-    rate = 2048 / (time.perf_counter() - t0)
-    n1 = int(min(n_sample, max(4096, rate * CPU_SINGLE_THREAD_SECONDS)))
-    t0 = time.perf_counter()
-    orc.perm_batch(inp[:20 * n1], 1)
-    t1 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    exp = orc.perm_batch(inp, cores)
-    tall = time.perf_counter() - t0
+
+    def time_build(o):
+        # single thread on a slice sized for >= 2 s (calibrated on 2 048 permutations), all cores on the whole sample
+        t0 = time.perf_counter()
+        o.perm_batch(inp[:20 * 2048], 1)
+        rate = 2048 / (time.perf_counter() - t0)
+        n1 = int(min(n_sample, max(4096, rate * CPU_SINGLE_THREAD_SECONDS)))
+        t0 = time.perf_counter()
+        o.perm_batch(inp[:20 * n1], 1)
+        t1 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        res = o.perm_batch(inp, cores)
+        return res, time.perf_counter() - t0, n1, t1
+
+    exp, tall, n1, t1 = time_build(orc)
+    builds = {"portable": {"flags": oracle_lib.PORTABLE_FLAGS, "value": n_sample / tall, "single_thread_value": n1 / t1}}
+    native, native_flags = oracle_lib.load_native()
+    native_ok = True
+    if native is not None:
+        exp_n, tall_n, n1_n, t1_n = time_build(native)
+        native_ok = bool((exp_n == exp).all())
+        builds["native"] = {"flags": native_flags, "value": n_sample / tall_n, "single_thread_value": n1_n / t1_n,
+                            "equals_portable_build": native_ok}
+    else:
+        builds["native"] = {"flags": oracle_lib.NATIVE_FLAGS, "unavailable": native_flags}
+    best = max((b for b in builds.values() if "value" in b), key=lambda b: b["value"])
+    best_1t = max((b for b in builds.values() if "value" in b), key=lambda b: b["single_thread_value"])
     # parity of the GPU path on the same inputs
     buf = H.gen_b(5 * n_sample, device)
     H.ScalarStrategy(kernel).perm(buf)
     got = buf.cpu().numpy().view(np.uint64).reshape(-1)
-    ok = bool((got == exp).all())
+    ok = bool((got == exp).all()) and native_ok
     return {
-        "value": n_sample / tall, "unit": "permutations/s", "cores": cores, "kind": "port",
-        "sample": "first %d permutations of the same generator-B workload, %d threads "
-                  "(C restatement of the reference CPU path, gcc -O3 -march=x86-64-v3)" % (n_sample, cores),
-        "single_thread_value": n1 / t1,
-        "single_thread_sample": "first %d permutations of the same workload, one thread, %.2f s" % (n1, t1),
-        "all_cores_seconds": tall,
+        "value": best["value"], "unit": "permutations/s", "cores": cores, "kind": "port",
+        "flags": best["flags"], "host_cpu": oracle_lib.host_cpu_model(),
+        "sample": "first %d permutations of the same generator-B workload, %d threads (C restatement of the reference CPU "
+                  "path; the better of two builds of the same source, see `builds`)" % (n_sample, cores),
+        "single_thread_value": best_1t["single_thread_value"], "single_thread_flags": best_1t["flags"],
+        "single_thread_sample": "first %d permutations of the same workload, one thread, >= %.1f s" % (n1, CPU_SINGLE_THREAD_SECONDS),
+        "all_cores_seconds": n_sample / best["value"],
+        "builds": builds,
     }, ok
 
 
@@ -214,17 +240,34 @@ def golden_merkle_root(n_leaves: int):
         return None
 
 
-def golden_block_digest(first_perm: int, n: int):
-    """The CPU oracle's digest of ALL outputs of perm(generator-B states [first_perm, first_perm + n)) -- committed for the
-    headline blocks (n = 2^26, first_perm a multiple of it: what rank g of an N-GPU run holds after its first launch;
-    tests/golden/kat.json `headline_2p26_blocks`, tools/oracle_block_digests.py).  None for any other range."""
-    if n != 1 << 26 or first_perm % n:
+def golden_range_digest(first_perm: int, n: int):
+    """The CPU oracle's digest (hades252_digest_dev / oracle_lib.digest_ref, GLOBAL word indices) of ALL outputs of
+    perm(generator-B states [first_perm, first_perm + n)), from the committed oracle runs -- or None when the range is not
+    a union of committed pieces.  Digests are additive over disjoint index ranges (limb-wise wrapping sums), and two
+    independent oracle runs are committed in tests/golden/kat.json: `headline_2p26_blocks` (2^26-state blocks 0 .. 7 =
+    states [0, 2^29): what rank g of a weak-scaling run holds after its first launch; tools/oracle_block_digests.py) and
+    `config5_2p30.oracle_shard_digests` (2^27-state shards 0 .. 7 = all of configs[4]; tools/oracle_config5_digest.py)."""
+    if n <= 0:
         return None
     try:
         with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
-            return json.load(f)["headline_2p26_blocks"]["blocks"].get(str(first_perm // n))
+            kat = json.load(f)
+        blocks = kat["headline_2p26_blocks"]["blocks"]
+        tables = (((1 << 26), [blocks.get(str(i)) for i in range(8)]),
+                  ((1 << 27), list(kat["config5_2p30"]["oracle_shard_digests"])))
     except Exception:
         return None
+    for piece, table in tables:
+        if first_perm % piece or n % piece:
+            continue
+        ids = range(first_perm // piece, (first_perm + n) // piece)
+        if ids[-1] >= len(table) or any(table[i] is None for i in ids):
+            continue
+        acc = [0, 0, 0, 0]
+        for i in ids:
+            acc = [(a + int(h, 16)) & 0xFFFFFFFFFFFFFFFF for a, h in zip(acc, table[i])]
+        return ["%016x" % a for a in acc]
+    return None
 
 
 def merkle_record(H, torch, device, log_leaves: int, reps: int = 5):
@@ -237,6 +280,7 @@ def merkle_record(H, torch, device, log_leaves: int, reps: int = 5):
     leaves = H.gen_b(n, device)
     scratch = torch.empty(max(_lib.lib().hades252_merkle_scratch_bytes(n, 4) // 8, 2), dtype=torch.int64, device=device)
     H.merkle_root(leaves, 4, tag, 1, scratch)
+    builds = 1                                      # (counted, so that a counter pass can divide its sums by it)
     ms = []
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -245,6 +289,7 @@ def merkle_record(H, torch, device, log_leaves: int, reps: int = 5):
         b.record()
         torch.cuda.synchronize()
         ms.append(a.elapsed_time(b))
+        builds += 1
     med = sorted(ms)[len(ms) // 2]
     nodes = (n - 1) // 3
     ach = MERKLE_BYTES_PER_NODE * nodes / (med * 1e-3) / 1e9
@@ -252,7 +297,7 @@ def merkle_record(H, torch, device, log_leaves: int, reps: int = 5):
     gold = golden_merkle_root(n)
     return {"workload": "arity-4 Poseidon Merkle tree over 2^%d leaves in HBM, root only (BASELINE configs[3]; tag 15, "
                         "digest word 1: external convention, parameters)" % log_leaves,
-            "tree_ms": med, "tree_ms_all": ms, "nodes": nodes, "nodes_per_s": nodes / (med * 1e-3),
+            "tree_ms": med, "tree_ms_all": ms, "trees_built": builds, "nodes": nodes, "nodes_per_s": nodes / (med * 1e-3),
             "root": root_hex,
             # the root of the LAST timed build against the CPU oracle's committed root of the same tree
             "root_matches_golden": None if gold is None else int(root_hex, 16) == gold,
@@ -269,9 +314,11 @@ def wire_format_record(H, torch, device, log_n=26):
     limbs = H.gen_b(n, device)
     out = torch.empty_like(limbs)
     canon = H.to_bytes(limbs)
+    launches = {"to_bytes": 1, "from_bytes": 0}     # (counted, so that a counter pass can divide its sums by it)
     rec = {"workload": "2^%d scalars per launch, 32 B in + 32 B out each" % log_n}
     for name, fn in (("to_bytes", lambda: H.to_bytes(limbs, out)), ("from_bytes", lambda: H.from_bytes(canon, out))):
         fn()
+        launches[name] += 1
         torch.cuda.synchronize()
         ms = []
         for _ in range(5):
@@ -281,11 +328,13 @@ def wire_format_record(H, torch, device, log_n=26):
             b.record()
             torch.cuda.synchronize()
             ms.append(a.elapsed_time(b))
+            launches[name] += 1
         med = sorted(ms)[2]
         ach = 64.0 * n / (med * 1e-3) / 1e9
         rec[name] = {"ms": med, "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_scalar": 64}}
     rec["round_trip_exact"] = bool(torch.equal(out, limbs))          # from_bytes(to_bytes(x)) == x on all 2^log_n scalars
+    rec["launches"] = launches
     return rec
 
 
@@ -297,6 +346,7 @@ def gadget_witness_record(H, torch, device, log_n=20):
     st = H.gen_b(5 * n, device)
     wires = torch.empty((H.witness_wires(), n, 4), dtype=torch.int64, device=device)
     H.perm_witness(st, out=wires)
+    launches = 1
     torch.cuda.synchronize()
     ms = []
     for _ in range(5):
@@ -306,13 +356,14 @@ def gadget_witness_record(H, torch, device, log_n=20):
         b.record()
         torch.cuda.synchronize()
         ms.append(a.elapsed_time(b))
+        launches += 1
     med = sorted(ms)[2]
     nw = wires.shape[0]
     last = torch.stack([wires[nw - 10 + 2 * j + 1] for j in range(5)], dim=1).reshape(-1)
     out = st.clone()
     H.ScalarStrategy().perm(out)
     ach = (160.0 + 32.0 * nw) * n / (med * 1e-3) / 1e9
-    rec = {"workload": "2^%d states, %d wires of 32 B each per state" % (log_n, nw), "ms": med,
+    rec = {"workload": "2^%d states, %d wires of 32 B each per state" % (log_n, nw), "ms": med, "launches": launches,
            "perms_per_s": n / (med * 1e-3), "last_rows_equal_perm": bool(torch.equal(last, out.reshape(-1))),
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_state": 160 + 32 * nw}}
@@ -321,6 +372,7 @@ def gadget_witness_record(H, torch, device, log_n=20):
     trace = torch.empty((67, n, 5, 4), dtype=torch.int64, device=device)
     stv = st.view(n, 5, 4)
     H.perm_trace(stv, out=trace)
+    launches = 1
     torch.cuda.synchronize()
     ms = []
     for _ in range(5):
@@ -330,9 +382,10 @@ def gadget_witness_record(H, torch, device, log_n=20):
         b.record()
         torch.cuda.synchronize()
         ms.append(a.elapsed_time(b))
+        launches += 1
     med = sorted(ms)[2]
     ach = 160.0 * 68 * n / (med * 1e-3) / 1e9
-    rec["trace"] = {"workload": "2^%d states, 67 states of 160 B written per state" % log_n, "ms": med,
+    rec["trace"] = {"workload": "2^%d states, 67 states of 160 B written per state" % log_n, "ms": med, "launches": launches,
                     "perms_per_s": n / (med * 1e-3), "last_round_equals_perm": bool(torch.equal(trace[66].reshape(-1), out.reshape(-1))),
                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_state": 160 * 68}}
@@ -452,22 +505,42 @@ def attach_traffic(roofline: dict, sec, key: str, algorithmic: float):
         roofline["traffic"] = None
 
 
+def ranks_agree(sharding, ok: bool, device) -> bool:
+    """AND over ranks of a LOCAL outcome, taken before a record's first collective: either every rank goes on or every rank
+    skips -- a rank that failed alone (out of memory on one GPU) must not leave the others waiting in a barrier."""
+    return sharding.reduce_min_int(1 if ok else 0, device) == 1
+
+
 def config5_record(args, H, torch, device, sharding, rank, world):
-    """BASELINE configs[4] on the ranks of this job (every rank calls this): 2^27 states per GPU at world size 8 (2^30 in
-    all), 3 timed launches, 2 048 states of every rank's shard against the CPU oracle, and the wrapping sum of the shard
-    digests after the FIRST launch against the CPU oracle's digest of the same 2^30 outputs (tests/golden/kat.json
-    `config5_2p30`; equal to the one-device digest recorded since round 2).  At any other world size (the one-GPU rehearsal of this path) the shard is
-    --perms-per-gpu states and rank 0 computes the one-device digest itself when the whole range is small."""
-    n = (1 << 27) if (world == 8 and (not args.single_device or args.config5_full_size)) else (args.perms_per_gpu or (1 << 20))
-    total = n * world
-    first_perm, _ = sharding.weak_shard(rank, n)
-    st = torch.empty((n, 5, 4), dtype=torch.int64, device=device)
-    H.gen_b(5 * n, device, first_elem=5 * first_perm, out=st.view(-1, 4))
-    check = ShardCheck(torch, st, first_perm, n, args.verify_sample)
+    """BASELINE configs[4] on the ranks of this job, at EVERY world size (every rank calls this): 2^30 states in all, rank g
+    owns [g 2^30 / N, (g + 1) 2^30 / N) -- 160 GiB on the one device at N = 1, 20 GiB per GPU at N = 8 -- so the driver's
+    1 / 2 / 4 / 8 runs give a STRONG-scaling curve for the config BASELINE names.  3 timed launches; 2 048 states of every
+    rank's shard against the CPU oracle; every rank's digest of ALL its outputs after the FIRST launch against the sum of
+    the oracle's committed shard digests it covers, and the wrapping sum over ranks against the oracle's digest of all
+    2^30 outputs (tests/golden/kat.json `config5_2p30`).  With --single-device (the one-GPU rehearsal of the multi-rank
+    path) the shard is --perms-per-gpu states and rank 0 computes the one-device digest itself."""
+    full = (not args.single_device) or args.config5_full_size
+    total = (1 << 30) if full else (args.perms_per_gpu or (1 << 20)) * world
+    first_perm, end = sharding.strong_shard(rank, world, total)
+    n = end - first_perm
+    st, check, err = None, None, None
+    try:                                             # local work only: nothing here may leave another rank waiting
+        free, _ = torch.cuda.mem_get_info()
+        if free < 160 * n + (2 << 30):
+            raise MemoryError("%d GiB of HBM free, the shard needs %d" % (free >> 30, (160 * n + (2 << 30)) >> 30))
+        st = torch.empty((n, 5, 4), dtype=torch.int64, device=device)
+        H.gen_b(5 * n, device, first_elem=5 * first_perm, out=st.view(-1, 4))
+        check = ShardCheck(torch, st, first_perm, n, args.verify_sample)
+        torch.cuda.synchronize()
+    except Exception as e:
+        err = repr(e)
+    if not ranks_agree(sharding, err is None, device):
+        del st, check
+        torch.cuda.empty_cache()
+        return {"skipped": "a rank could not set its shard up (rank 0: %s)" % err} if rank == 0 else None
     strat = H.ScalarStrategy(args.kernel)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
     digest1 = None
-    torch.cuda.synchronize()
     sharding.barrier(device)
     t0 = time.perf_counter()
     for i, (a, b) in enumerate(evs):
@@ -481,11 +554,16 @@ def config5_record(args, H, torch, device, sharding, rank, world):
     wall = sharding.reduce_max(time.perf_counter() - t0, device)
     ms = sharding.gather_floats(sum(a.elapsed_time(b) for a, b in evs) / 3, device)
     ok = sharding.reduce_min_int(1 if check.after(3) else 0, device) == 1
+    # this rank's outputs, ALL of them, against the oracle's committed digests of the same index range
+    mine = ["%016x" % (d & 0xFFFFFFFFFFFFFFFF) for d in digest1]
+    gold_mine = golden_range_digest(first_perm, n) if total == 1 << 30 else None
+    shards_covered = sharding.reduce_sum_int(1 if gold_mine is not None else 0, device)
+    shards_ok = sharding.reduce_sum_int(1 if (gold_mine is not None and mine == gold_mine) else 0, device)
     combined = ["%016x" % d for d in sharding.combine_digests(digest1, device)]
-    del st
+    del st, check
     torch.cuda.empty_cache()
     gold, gold_src = None, None
-    if total == 1 << 30 and n == 1 << 27:
+    if total == 1 << 30:
         try:
             with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
                 gold = json.load(f)["config5_2p30"]["oracle_digest"]
@@ -502,17 +580,21 @@ def config5_record(args, H, torch, device, sharding, rank, world):
         torch.cuda.empty_cache()
     if rank != 0:
         return None
-    return {"workload": "%d states per GPU x %d GPUs = %s states (BASELINE configs[4]%s), generator B, in place, 3 timed "
-                        "launches" % (n, world, ("2^%d" % (total.bit_length() - 1)) if total & (total - 1) == 0 else str(total),
-                                      "" if total == 1 << 30 else " at rehearsal size"),
-            "perms_per_gpu": n, "total_perms": total, "kernel": kernel_of(args.kernel, n),
-            "kernel_ms_per_rank": ms, "perms_per_s_per_rank": [n / (x * 1e-3) for x in ms],
-            "value": total / (max(ms) * 1e-3), "unit": "permutations/s (whole node, slowest rank's mean launch)",
+    n_max = -(-total // world)
+    return {"workload": "%s states in all over %d GPU(s), %d per GPU (BASELINE configs[4]%s), generator B, in place, 3 timed "
+                        "launches" % (("2^%d" % (total.bit_length() - 1)) if total & (total - 1) == 0 else str(total), world,
+                                      n_max, "" if total == 1 << 30 else " at rehearsal size"),
+            "scaling": "strong", "perms_per_gpu": n_max, "total_perms": total, "kernel": kernel_of(args.kernel, n_max),
+            "kernel_ms_per_rank": ms, "perms_per_s_per_rank": [n_max / (x * 1e-3) for x in ms],
+            "value": total / (max(ms) * 1e-3), "unit": "permutations/s (whole job, slowest rank's mean launch)",
             "wall_s_3_launches_and_digest": wall,
             "parity_vs_cpu_sample": ok, "digest": combined,
             "digest_matches_one_device": None if gold is None else combined == list(gold),
             # at full size the committed digest is the CPU oracle's over all 2^30 outputs: every output bit-exact, not a sample
             "digest_matches_oracle_at_full_size": (combined == list(gold)) if (gold is not None and total == 1 << 30) else None,
+            # ... and rank by rank (a rank's range is a union of the oracle's eight 2^27-state shards when N divides 8)
+            "shard_digests_match_oracle": None if shards_covered == 0 else shards_ok == shards_covered,
+            "shards_covered": "%d of %d ranks" % (shards_covered, world),
             "golden": gold_src}
 
 
@@ -612,6 +694,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--perms-per-gpu", type=int, default=0,
                     help="default: 2^26 at every N (BASELINE configs[2]); 134217728 = configs[4] (2^30 over 8 GPUs)")
+    ap.add_argument("--total-perms", type=int, default=0,
+                    help="strong scaling: this many permutations IN ALL, sharded over the ranks (1073741824 = BASELINE "
+                         "configs[4] at any N); overrides --perms-per-gpu")
     ap.add_argument("--kernel", type=int, default=0,
                     help="0 default dispatch (k_perm_fast above 16384 states), 1 literal, 2 fast, 3 coop (five waves "
                          "per state), 4 lanes (lane-split low latency)")
@@ -669,9 +754,14 @@ def main():
     if args.workload == "merkle":
         return bench_merkle(args, H, torch, device, sharding, rank, world)
 
-    n = args.perms_per_gpu or (1 << 26)
-    kernel_name = kernel_of(args.kernel, n)
-    first_perm, _ = sharding.weak_shard(rank, n)
+    strong = args.total_perms > 0
+    if strong:
+        first_perm, end = sharding.strong_shard(rank, world, args.total_perms)
+        n, n_max = end - first_perm, -(-args.total_perms // world)
+    else:
+        n = n_max = args.perms_per_gpu or (1 << 26)
+        first_perm, _ = sharding.weak_shard(rank, n)
+    kernel_name = kernel_of(args.kernel, n_max)
     strat = H.ScalarStrategy(args.kernel)
     states = torch.empty((n, 5, 4), dtype=torch.int64, device=device)
     H.gen_b(5 * n, device, first_elem=5 * first_perm, out=states.view(-1, 4))
@@ -680,7 +770,7 @@ def main():
     # the parity launch (untimed, before the warm-up): EVERY output of this rank's block against the oracle, through the
     # 256-bit position-dependent digest the oracle computed over the same 2^26 states (headline configuration only)
     strat.perm(states)
-    gold_block = golden_block_digest(first_perm, n)
+    gold_block = golden_range_digest(first_perm, n)
     block_ok = None
     if gold_block is not None:
         block_ok = ["%016x" % (d & 0xFFFFFFFFFFFFFFFF) for d in H.digest(states, first_index=20 * first_perm)] == list(gold_block)
@@ -707,31 +797,38 @@ def main():
     # the timed launches themselves, checked on every rank: sampled states after warm-up + timed steps
     rank_ok = check.after(1 + args.warmup + args.steps) and block_ok is not False
     all_ok = sharding.reduce_min_int(1 if rank_ok else 0, device) == 1
-    blocks_checked = sharding.reduce_sum_int(1 if block_ok else 0, device)
+    blocks_covered = sharding.reduce_sum_int(1 if block_ok is not None else 0, device)
+    blocks_ok = sharding.reduce_sum_int(1 if block_ok else 0, device)
     digest = sharding.combine_digests(H.digest(states, first_index=20 * first_perm), device)
 
     del states, check
     torch.cuda.empty_cache()
     # the records every rank takes part in (N > 1): configs[4] and the sharded tree with its one exchange step
     multi = {}
-    if world > 1 and not args.no_secondary:
-        # (BASELINE configs[4] proper needs 8 ranks; at any other world size the same code runs at rehearsal size)
-        c5_name = ("config5_2p30" if (world == 8 and (not args.single_device or args.config5_full_size))
-                   else "config5_rehearsal")
-        for name, fn in ((c5_name, lambda: config5_record(args, H, torch, device, sharding, rank, world)),
-                         ("merkle_2p24_sharded", lambda: merkle_sharded_record(H, torch, device, sharding, rank, world))):
+    if not args.no_secondary:
+        # BASELINE configs[4] at this world size (N = 1 included: the strong-scaling curve needs its first point) unless the
+        # headline already IS that measurement; with --single-device the same code at rehearsal size
+        recs = []
+        if not (strong and args.total_perms == 1 << 30):
+            c5_name = "config5_2p30" if ((not args.single_device) or args.config5_full_size) else "config5_rehearsal"
+            recs.append((c5_name, lambda: config5_record(args, H, torch, device, sharding, rank, world)))
+        if world > 1:
+            recs.append(("merkle_2p24_sharded", lambda: merkle_sharded_record(H, torch, device, sharding, rank, world)))
+        for name, fn in recs:
             try:
                 multi[name] = fn()
-            except ValueError as e:          # a world size the tree does not split over: the same on every rank, no collective left open
-                multi[name] = {"error": repr(e)}
+            except Exception as e:           # (local failures are agreed on inside the records, before their first collective;
+                multi[name] = {"error": repr(e)}   # a ValueError -- a world size the tree does not split over -- is the same on every rank)
     backend_name = sharding.backend_name()
     sharding.shutdown(device)                # the last collective: from here on rank 0 works alone
     if rank != 0:
         if not rank_ok:
             raise SystemExit("rank %d: GPU output differs from the CPU oracle" % rank)
         return
-    total_perms = n * world * args.steps
+    per_step = args.total_perms if strong else n * world
+    total_perms = per_step * args.steps
     value = total_perms / elapsed
+    n = n_max                                   # (strong scaling with N not dividing T: shards differ by one state)
     achieved = ALGO_BYTES_PER_PERM * n / (kernel_ms_max * 1e-3) / 1e9
     traffic, traffic_source = None, None
     prof, sec_prof = profile_record(build, kernel_name, n)
@@ -744,13 +841,17 @@ def main():
     out = {
         "metric": "Hades252 permutations/sec (WIDTH=5, BLS12-381 Fr)",
         "value": value, "unit": "permutations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-        "config": {"workload": ("2^%d independent WIDTH=5 permutations per GPU, in place in HBM (BASELINE %s; generator "
-                                "B, Montgomery-limb AoS records)"
-                                % (n.bit_length() - 1, "configs[4]: 2^30 over 8 GPUs" if (world == 8 and n == 1 << 27)
-                                   else "configs[2]")) if pow2 else "%d permutations per GPU" % n,
-                   "perms_per_gpu": n, "total_perms_per_step": n * world, "state_bytes": 160,
+        "config": {"workload": (("%s independent WIDTH=5 permutations IN ALL, sharded over %d GPU(s): %d per GPU, in place in "
+                                 "HBM (%sgenerator B, Montgomery-limb AoS records)"
+                                 % (("2^%d" % (per_step.bit_length() - 1)) if per_step & (per_step - 1) == 0 else str(per_step),
+                                    world, n, "BASELINE configs[4]; " if per_step == 1 << 30 else "")) if strong else
+                                ("2^%d independent WIDTH=5 permutations per GPU, in place in HBM (BASELINE %s; generator "
+                                 "B, Montgomery-limb AoS records)"
+                                 % (n.bit_length() - 1, "configs[4]: 2^30 over 8 GPUs" if (world == 8 and n == 1 << 27)
+                                    else "configs[2]")) if pow2 else "%d permutations per GPU" % n),
+                   "perms_per_gpu": n, "total_perms_per_step": per_step, "state_bytes": 160,
                    "kernel": kernel_name,
                    "sharding": "contiguous range per rank, no collective"},
         "per_gpu": {"value": value / world, "unit": "permutations/s",
@@ -772,10 +873,12 @@ def main():
                          "the timed kernel and compared with the CPU oracle applied as many times; AND over ranks"
                          % (args.verify_sample, 1 + args.warmup + args.steps),
         # all 2^26 outputs of the first launch, on every rank whose block the oracle's digests cover (blocks 0 .. 7)
-        "parity_all_outputs_first_launch": (blocks_checked == world) if blocks_checked else None,
+        # (null = no rank's range is covered by a committed oracle digest; false = a covered rank's digest differs)
+        "parity_all_outputs_first_launch": (blocks_ok == blocks_covered) if blocks_covered else None,
         "parity_all_outputs": "digest (hades252_digest_dev, global indices) of ALL outputs of each rank's first launch == the CPU "
-                              "oracle's digest of the same 2^26 states (tests/golden/kat.json headline_2p26_blocks); ranks "
-                              "covered: %d of %d; a mismatch fails the job through parity_vs_cpu_sample" % (blocks_checked, world),
+                              "oracle's digest of the same states (tests/golden/kat.json headline_2p26_blocks / config5_2p30 "
+                              "shards, summed over the pieces a rank's range covers); ranks covered: %d of %d, equal: %d; a "
+                              "mismatch fails the job through parity_vs_cpu_sample" % (blocks_covered, world, blocks_ok),
     }
     if prof and prof.get("valu_instructions_per_wave"):
         # instructions per wave (= per 64 permutations... per lane: per permutation) from the counters of the keyed record
@@ -829,8 +932,10 @@ def main():
         if ms_.get("root_matches_golden") is False:
             wrong.append("the SHARDED 2^24-leaf Merkle root differs from the CPU oracle's committed root")
         c5 = sec.get("config5_2p30") or sec.get("config5_rehearsal") or {}
-        if c5.get("parity_vs_cpu_sample") is False or c5.get("digest_matches_one_device") is False:
-            wrong.append("configs[4]: the shards differ from the oracle sample or from the one-device digest")
+        if (c5.get("parity_vs_cpu_sample") is False or c5.get("digest_matches_one_device") is False
+                or c5.get("shard_digests_match_oracle") is False):
+            wrong.append("configs[4]: the shards differ from the oracle sample, from the oracle's shard digests or from the "
+                         "one-device digest")
     print(json.dumps(out), flush=True)
     if not all_ok:
         raise SystemExit("GPU output differs from the CPU oracle")

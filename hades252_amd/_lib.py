@@ -38,6 +38,7 @@ SIGNATURES = {
     "hades252_kernel_name": (c_char_p, [c_int, c_size_t]),
     "hades252_trim": (c_int, []),
     "hades252_pool_bytes": (c_size_t, []),
+    "hades252_stage_threads": (c_int, [c_int]),
     "hades252_fault_inject": (c_int, [c_char_p]),
     "hades252_perm_batch": (c_int, [c_void_p, c_size_t]),
     "hades252_perm_batch_bytes": (c_int, [c_void_p, c_size_t]),

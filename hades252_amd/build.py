@@ -22,9 +22,16 @@ LIB = os.path.join(CSRC, "libhades252.so")
 STAMP = LIB + ".stamp"
 LOCK = LIB + ".lock"
 SOURCES = ["hades252.hip"]
-DEPS = ["hades252.hip", "fr32.hpp", "staging.hpp", "hades_literal.hpp", "hades_fast.hpp", "k_perm_fast.hpp", "hades_coop.hpp", "hades_lanes.hpp",
-        "device_tables.hpp", "kernels_perm.hpp", "kernels_merkle.hpp", "kernels_sponge.hpp", "kernels_aux.hpp",
-        "hades_constants.inc", os.path.join("..", "..", "include", "hades252.h")]
+# device code: arithmetic, kernels, generated tables
+DEVICE_DEPS = ["fr32.hpp", "staging.hpp", "hades_literal.hpp", "hades_fast.hpp", "k_perm_fast.hpp", "hades_coop.hpp", "hades_lanes.hpp",
+               "device_tables.hpp", "kernels_perm.hpp", "kernels_merkle.hpp", "kernels_sponge.hpp", "kernels_aux.hpp",
+               "hades_constants.inc"]
+# host code that decides WHAT is launched and with which geometry / LDS / level-fusion policy: a kernel's traffic per launch
+# and the launches that make a tree depend on it
+LAUNCH_POLICY_DEPS = ["launch.hpp", "abi_perm.hpp", "abi_merkle.hpp", "abi_sponge.hpp"]
+# host plumbing (error / fault hook, page-locked memory, pipe pool, chunk pipeline, one-shot host callers, generators)
+HOST_DEPS = ["hades252.hip", "host_fault.hpp", "abi_util.hpp", "host_pin.hpp", "host_pool.hpp", "host_pipe.hpp", "host_callers.hpp"]
+DEPS = HOST_DEPS + LAUNCH_POLICY_DEPS + DEVICE_DEPS + [os.path.join("..", "..", "include", "hades252.h")]
 # what the dominant kernel (k_perm_fast) is made of: profiles recorded for it stay valid while these are unchanged
 PERM_FAST_DEPS = ["fr32.hpp", "staging.hpp", "hades_fast.hpp", "k_perm_fast.hpp"]
 # ... plus these tables of hades_constants.inc (other kernels' tables may change without touching k_perm_fast)
@@ -61,12 +68,13 @@ def perm_fast_hash() -> str:
 
 
 def device_source_hash() -> str:
-    """Hash of everything that determines the DEVICE code of every kernel: the kernel headers, the generated tables and the
-    flags -- not the host code of hades252.hip (launch policy, pools, the C ABI), whose edits leave a kernel's traffic per
-    launch as it was.  Keys the committed counter records of the kernels other than k_perm_fast
-    (profiles/hbm_traffic.json `secondary_kernels`)."""
+    """Hash of everything that determines what a launch (or a tree build: a SEQUENCE of launches) moves through HBM: the
+    device code of every kernel (kernel headers, generated tables, flags) AND the host code that picks kernels, grids, LDS
+    sizes and the level / fusion policy of a tree (launch.hpp, abi_*.hpp) -- not the host plumbing (pools, pipes, page
+    locking, the fault hook), whose edits leave traffic per launch as it was.  Keys the committed counter records of the
+    kernels other than k_perm_fast (profiles/hbm_traffic.json `secondary_kernels`)."""
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    for d in sorted(x for x in DEPS if x.endswith((".hpp", ".inc"))):
+    for d in sorted(DEVICE_DEPS + LAUNCH_POLICY_DEPS):
         with open(os.path.join(CSRC, d), "rb") as f:
             h.update(d.encode() + b"\0" + f.read())
     return h.hexdigest()

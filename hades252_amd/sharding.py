@@ -33,11 +33,27 @@ def weak_shard(rank: int, per_rank: int) -> Tuple[int, int]:
     return rank * per_rank, (rank + 1) * per_rank
 
 
+def strong_shard(rank: int, world: int, n_total: int) -> Tuple[int, int]:
+    """Strong scaling: `n_total` permutations in all (BASELINE configs[4]: 2^30), rank g owns the contiguous range
+    [g n / W, (g + 1) n / W) -- the split of SURVEY.md section 8(e); sizes differ by at most one."""
+    return shard_range(rank, world, n_total)
+
+
 def init_process_group(backend: str):
+    """Rendezvous on the launcher's MASTER_ADDR / MASTER_PORT.  A job of several ranks must be told its port (every rank
+    has to name the same one: torchrun and bench.py's own launcher both export it); a lone rank picks a free port
+    itself, so that two single-rank jobs on one host never collide on a hard-coded default."""
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:
+            if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+                raise RuntimeError("MASTER_PORT is not set: a multi-rank job gets it from its launcher "
+                                   "(torch.distributed.run --master-port P, or `python bench.py --gpus N`)")
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         dist.init_process_group(backend=backend)
     return dist
 
@@ -174,8 +190,9 @@ def gather_strings(text: str, device="cpu", width: int = 96) -> List[str]:
 
 def device_identity(torch, index: int) -> str:
     """What tells two physical GPUs apart: PCI address (domain:bus:device.function) and, where the runtime exposes it, the
-    device UUID.  From torch's device properties; the PCI address falls back to hipDeviceGetPCIBusId of the HIP runtime
-    this process has already loaded."""
+    device UUID.  From torch's device properties only: asking the HIP runtime directly would mean dlopen-ing a
+    libamdhip64 by name, which need not be the copy torch has mapped (a second runtime in the rank process).  Without a
+    PCI address the answer is "unknown device N", which `distinct_devices` treats as NOT distinct."""
     parts = []
     try:
         p = torch.cuda.get_device_properties(index)
@@ -188,15 +205,6 @@ def device_identity(torch, index: int) -> str:
         parts.append(str(getattr(p, "name", "")))
     except Exception:
         pass
-    if not any(x.startswith("pci") for x in parts):
-        try:
-            import ctypes
-            hip = ctypes.CDLL("libamdhip64.so")
-            buf = ctypes.create_string_buffer(64)
-            if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
-                parts.insert(0, "pci " + buf.value.decode("ascii", "replace").lower())
-        except Exception:
-            pass
     return "; ".join(x for x in parts if x) or "unknown device %d" % index
 
 

@@ -169,6 +169,11 @@ int hades252_warm_up(size_t n_perms_hint);
  * one per call in flight) and a staging call reuses a pipe that owns one before allocating another; trim frees them. */
 int hades252_trim(void);
 size_t hades252_pool_bytes(void);
+/* Helper threads per copy direction a host-pointer call on ORDINARY memory uses when it is one of n_workers concurrent
+ * calls (the worker threads of the _multi entry points; 1 = a plain hades252_perm_batch): HADES252_STAGE_THREADS
+ * (environment, 1 .. 6, default 3), capped so that n_workers x 2 directions x threads never exceeds the CPUs this process
+ * may run on (sched_getaffinity), at least 1. */
+int hades252_stage_threads(int n_workers);
 
 /* ---- failure contract of the host-pointer entry points, and the hook that tests it -------------------------------
  * On HADES252_ERR_HIP from hades252_perm_batch* every 160-byte state of the caller's buffer holds EITHER its input OR
@@ -186,7 +191,7 @@ size_t hades252_pool_bytes(void);
  * process start).  Disarmed cost: one relaxed load per wrapped call.
  * HADES252_TEST_MAX_LAUNCH (tests only; read at the first call of hades252_perm_batch_dev*) lowers the number of states
  * one kernel launch of that entry point takes from 2^30, so that its multi-launch loop can be exercised on a few
- * thousand states. */
+ * thousand states; values below 256 are ignored. */
 int hades252_fault_inject(const char *spec);
 
 /* ---- the callers of perm, host memory in, host memory out -------------------------------------------------

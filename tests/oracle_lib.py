@@ -51,6 +51,56 @@ def build():
     return SO
 
 
+PORTABLE_FLAGS = "gcc -O3 -march=x86-64-v3"
+NATIVE_FLAGS = "gcc -O3 -march=native"
+
+
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def build_native():
+    """The oracle's source compiled `-O3 -march=native` ON THIS HOST, for the cpu_baseline TIMING of
+    bench.py only -- the checker stays the portable build.  Rebuilt whenever the sources or the host's CPU model change
+    (the tree travels between machines).  Returns the path, or None when the host cannot build or run it."""
+    import fcntl
+    import hashlib
+    build()
+    h = hashlib.sha256(host_cpu_model().encode())
+    for f in ("hades_oracle.c", "hades_oracle_constants.h", "Makefile"):
+        with open(os.path.join(ORACLE_DIR, f), "rb") as fh:
+            h.update(fh.read())
+    want = h.hexdigest()
+    out_dir = os.path.join(ORACLE_DIR, "_build")
+    so = os.path.join(out_dir, "libhades_oracle_native.so")
+    stamp = so + ".stamp"
+
+    def fresh():
+        return os.path.exists(so) and os.path.exists(stamp) and open(stamp).read().strip() == want
+
+    try:
+        with open(os.path.join(out_dir, ".lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if not fresh():
+                    subprocess.run(["make", "-B", "-C", ORACLE_DIR, "native"], check=True, stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.DEVNULL)
+                    with open(stamp + ".tmp", "w") as f:
+                        f.write(want + "\n")
+                    os.replace(stamp + ".tmp", stamp)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
+        return so
+    except Exception:
+        return None
+
+
 def limbs_of(m):
     return [(m >> (64 * k)) & M64 for k in range(4)]
 
@@ -251,6 +301,17 @@ class Oracle:
 
 def load():
     return Oracle(build())
+
+
+def load_native():
+    """(Oracle tuned for this host, flags) for TIMING, or (None, reason)."""
+    so = build_native()
+    if so is None:
+        return None, "could not build -march=native here"
+    try:
+        return Oracle(so), NATIVE_FLAGS
+    except OSError as e:
+        return None, repr(e)
 
 
 def digest_ref(words, first_index=0):

@@ -77,3 +77,41 @@ def test_merkle_shape_helpers():
     assert H.merkle_level_sizes(2, 4) == [1] and H.merkle_level_sizes(5, 2) == [3, 2, 1]
     assert sum(H.merkle_level_sizes(4 ** 7, 4)) == (4 ** 7 - 1) // 3
     assert set(H.SPONGE_PRESETS) == {"sponge/pad10", "merkle/arity4"}
+
+
+_STAGE_CHILD = r"""
+import ctypes, os, sys
+cpus = sorted(os.sched_getaffinity(0))[:int(sys.argv[1])]
+os.sched_setaffinity(0, cpus)
+lib = ctypes.CDLL(sys.argv[2])
+lib.hades252_stage_threads.restype = ctypes.c_int
+lib.hades252_stage_threads.argtypes = [ctypes.c_int]
+print(len(cpus), *[lib.hades252_stage_threads(w) for w in (1, 2, 4, 8, 64, 0, -3)])
+"""
+
+
+def test_staging_threads_never_outnumber_the_usable_cpus():
+    """an 8-GPU hades252_perm_batch_multi call used 3 + 3 helper threads per worker whatever the
+    process may run on.  hades252_stage_threads(workers) = min(HADES252_STAGE_THREADS, cpus / (2 workers)), >= 1 -- pure
+    host arithmetic (no HIP call), checked under restricted affinity masks in child processes."""
+    import subprocess
+    from hades252_amd import build
+    lib = build.build(verbose=False)
+    have = len(os.sched_getaffinity(0))
+    for n_cpus in sorted({1, 2, 4, 6, 8, have}):
+        if n_cpus > have:
+            continue
+        for env_threads in (None, "6", "1"):
+            env = dict(os.environ)
+            env.pop("HADES252_STAGE_THREADS", None)
+            if env_threads:
+                env["HADES252_STAGE_THREADS"] = env_threads
+            r = subprocess.run([sys.executable, "-c", _STAGE_CHILD, str(n_cpus), lib], capture_output=True, text=True,
+                               env=env, timeout=120)
+            assert r.returncode == 0, r.stderr[-800:]
+            got = [int(x) for x in r.stdout.split()]
+            cpus, per_workers = got[0], got[1:]
+            configured = int(env_threads or 3)
+            for workers, t in zip((1, 2, 4, 8, 64, 1, 1), per_workers):         # (0 and negative mean one caller)
+                assert t == max(1, min(configured, cpus // (2 * workers))), (cpus, env_threads, workers, t)
+                assert t == 1 or workers * 2 * t <= cpus

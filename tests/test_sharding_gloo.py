@@ -178,3 +178,105 @@ def test_device_identity_helpers():
     assert not sharding.distinct_devices(["unknown device 0", "unknown device 0"])
     assert sharding.distinct_devices(["only one"])
     assert sharding.gather_strings("solo") == ["solo"] and sharding.world_size() == 1 and sharding.backend_name() == "none"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Strong scaling (bench.py --total-perms / secondary.config5_2p30 at every N): T states in all, rank g owns
+# [g T / N, (g + 1) T / N).  World size 8 over gloo with the ORACLE in place of the device call: the shards tile the
+# range, every rank's digest of its outputs (global word indices) sums to the digest of the whole batch, and the
+# pre-collective agreement (`ranks_agree`) makes all ranks skip together when one of them fails alone.
+# ---------------------------------------------------------------------------------------------------------------
+def _strong_worker(rank, world, port, total, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    import bench
+    sharding.init_process_group("gloo")
+    orc = oracle_lib.load()
+    b, e = sharding.strong_shard(rank, world, total)
+    out = orc.perm_batch(orc.gen_b(5 * b, 5 * (e - b)), 1)
+    mine = oracle_lib.digest_ref(out, 20 * b)
+    comb = sharding.combine_digests(mine)
+    sizes = sharding.gather_floats(float(e - b))
+    # one rank fails its local set-up: every rank must learn it BEFORE the record's first collective
+    agree_all = bench.ranks_agree(sharding, True, "cpu")
+    agree_one_down = bench.ranks_agree(sharding, rank != 5, "cpu")
+    q.put((rank, (b, e), comb, sizes, agree_all, agree_one_down))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total", [(8, 8 * 96), (8, 1001), (2, 640)])
+def test_strong_scaling_shards_over_gloo(world, total):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    orc = oracle_lib.load()
+    whole = oracle_lib.digest_ref(orc.perm_batch(orc.gen_b(0, 5 * total)), 0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() + 13 * world + total) % 250
+    procs = [ctx.Process(target=_strong_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    spans = [r[1] for r in res]
+    assert spans[0][0] == 0 and spans[-1][1] == total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    for rank, span, comb, sizes, agree_all, agree_one_down in res:
+        assert comb == whole                                           # every rank holds the whole job's digest
+        assert sizes == [float(e - b) for b, e in spans] and max(sizes) - min(sizes) <= 1
+        assert agree_all is True and agree_one_down is (world <= 5)    # rank 5 exists only at world 8
+
+
+def test_committed_oracle_digests_cover_every_strong_shard():
+    """bench.golden_range_digest: the digest of ALL outputs of perm(generator-B states [b, b + n)) as a sum of committed
+    oracle pieces.  For BASELINE configs[4] (2^30 states) at N = 1, 2, 4, 8 every rank's range is covered, the per-rank
+    digests add up to the oracle's digest of the whole batch, and the two independent oracle runs (2^26-state blocks of the
+    headline, 2^27-state shards of configs[4]) agree wherever both cover a range."""
+    import json
+    import bench
+    with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
+        kat = json.load(f)
+    total = 1 << 30
+    whole = [int(h, 16) for h in kat["config5_2p30"]["oracle_digest"]]
+    for world in (1, 2, 4, 8):
+        acc = [0, 0, 0, 0]
+        for rank in range(world):
+            b, e = sharding.strong_shard(rank, world, total)
+            d = bench.golden_range_digest(b, e - b)
+            assert d is not None, (world, rank)
+            acc = [(a + int(h, 16)) & sharding.M64 for a, h in zip(acc, d)]
+        assert acc == whole, world
+    assert bench.golden_range_digest(7 << 27, 1 << 27) == kat["config5_2p30"]["oracle_shard_digests"][7]
+    # weak-scaling headline: rank g's block g; blocks 2k, 2k + 1 (one oracle run) == shard k (another oracle run)
+    for g in range(8):
+        assert bench.golden_range_digest(g << 26, 1 << 26) == kat["headline_2p26_blocks"]["blocks"][str(g)]
+    for k in range(4):
+        two = [(int(a, 16) + int(b, 16)) & sharding.M64 for a, b in zip(bench.golden_range_digest((2 * k) << 26, 1 << 26),
+                                                                        bench.golden_range_digest((2 * k + 1) << 26, 1 << 26))]
+        assert ["%016x" % x for x in two] == kat["config5_2p30"]["oracle_shard_digests"][k]
+        assert bench.golden_range_digest(k << 27, 1 << 27) == kat["config5_2p30"]["oracle_shard_digests"][k]
+    # not covered: unaligned, beyond the committed range, a world size that does not divide 8, empty
+    for b, n in ((1, 1 << 26), (8 << 26, 1 << 26), (0, (1 << 30) // 3), (0, 0), (1 << 30, 1 << 27), (0, 1 << 20)):
+        assert bench.golden_range_digest(b, n) is None, (b, n)
+
+
+def test_lone_rank_picks_a_free_port_and_a_job_must_be_told_its_port(monkeypatch):
+    """VERDICT r5 weak #4: no hard-coded default MASTER_PORT."""
+    src = open(os.path.join(ROOT, "hades252_amd", "sharding.py")).read()
+    assert "29511" not in src
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        sharding.init_process_group("gloo")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    sharding.init_process_group("gloo")
+    try:
+        assert 1024 < int(os.environ["MASTER_PORT"]) < 65536 and sharding.world_size() == 1
+        assert sharding.reduce_max(2.5) == 2.5 and sharding.combine_digests([1, 2, 3, sharding.M64]) == [1, 2, 3, sharding.M64]
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("MASTER_PORT", None)

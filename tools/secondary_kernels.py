@@ -2,8 +2,8 @@
 wire-format kernels at 2^26 scalars, the gadget witness and the per-round trace at 2^20 states -- bench.py's own record
 functions, nothing else.  Run plain for the timings (stdout: one JSON line), and under `rocprofv3 --pmc FETCH_SIZE` /
 `--pmc WRITE_SIZE` in separate passes (tools/profile_round.sh) for the HBM byte counts tools/summarize_profile.py turns
-into `secondary_kernels` of profiles/hbm_traffic.json.  The number of launches of every kind is printed so that the
-summary can divide the counter sums by it."""
+into `secondary_kernels` of profiles/hbm_traffic.json.  The number of launches of every kind is COUNTED by the record
+functions themselves and printed, so that the summary divides the counter sums by what really ran."""
 import json
 import os
 import sys
@@ -20,12 +20,13 @@ out = {}
 rec, leaves = bench.merkle_record(H, torch, dev, 24, reps=5)
 del leaves
 torch.cuda.empty_cache()
-out["merkle_2p24"] = {"tree_ms": rec["tree_ms"], "trees_built": 6, "root_matches_golden": rec["root_matches_golden"]}
+out["merkle_2p24"] = {"tree_ms": rec["tree_ms"], "trees_built": rec["trees_built"], "root_matches_golden": rec["root_matches_golden"]}
 w = bench.wire_format_record(H, torch, dev)
 torch.cuda.empty_cache()
 # (to_bytes runs once more than from_bytes: it also produces the canonical input of from_bytes)
-out["wire_format"] = {"to_bytes_ms": w["to_bytes"]["ms"], "from_bytes_ms": w["from_bytes"]["ms"], "to_bytes_launches": 7,
-                      "from_bytes_launches": 6}
+out["wire_format"] = {"to_bytes_ms": w["to_bytes"]["ms"], "from_bytes_ms": w["from_bytes"]["ms"], "to_bytes_launches": w["launches"]["to_bytes"],
+                      "from_bytes_launches": w["launches"]["from_bytes"]}
 g = bench.gadget_witness_record(H, torch, dev)
-out["gadget_witness"] = {"witness_ms": g["ms"], "trace_ms": g["trace"]["ms"], "witness_launches": 6, "trace_launches": 6}
+out["gadget_witness"] = {"witness_ms": g["ms"], "trace_ms": g["trace"]["ms"], "witness_launches": g["launches"],
+                         "trace_launches": g["trace"]["launches"]}
 print(json.dumps(out), flush=True)

@@ -43,7 +43,7 @@ def perm_fast_hash_at(commit: str) -> str:
 
 def device_source_hash_at(commit: str) -> str:
     h = hashlib.sha256(" ".join(build.FLAGS).encode())
-    for d in sorted(x for x in build.DEPS if x.endswith((".hpp", ".inc"))):
+    for d in sorted(build.DEVICE_DEPS + build.LAUNCH_POLICY_DEPS):
         h.update(d.encode() + b"\0" + _show(commit, CSRC_REL + "/" + d))
     return h.hexdigest()
 

@@ -81,6 +81,10 @@ def secondary_kernels(build):
         if not cs["FETCH_SIZE"] or not cs["WRITE_SIZE"]:
             continue
         if g == "merkle_2p24_tree":
+            if len(cs["FETCH_SIZE"]) % trees or len(cs["WRITE_SIZE"]) % trees:     # the counted builds must tile the dispatches
+                print("secondary merkle_2p24_tree: %d / %d dispatches do not divide into %d trees -- record dropped"
+                      % (len(cs["FETCH_SIZE"]), len(cs["WRITE_SIZE"]), trees))
+                continue
             rd = sum(cs["FETCH_SIZE"]) / trees * 1024 * 2
             wr = sum(cs["WRITE_SIZE"]) / trees * 1024
             n = trees
@@ -89,6 +93,8 @@ def secondary_kernels(build):
             wr = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024
             n = len(cs["FETCH_SIZE"])
         res[g] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr, "launches_or_trees_averaged": n}
+        if g == "merkle_2p24_tree":
+            res[g]["launches_per_tree"] = len(cs["FETCH_SIZE"]) // trees
         print("secondary %-18s read %.5g B  write %.5g B  total %.5g B  (n=%d)" % (g, rd, wr, rd + wr, n))
     return res
 
