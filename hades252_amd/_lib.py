@@ -65,6 +65,8 @@ SIGNATURES = {
                                          POINTER(c_size_t)]),
     "hades252_perm_trace_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "hades252_perm_trace_dev_ex": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
+    "hades252_perm_trace_scaled_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hades252_perm_trace_scale_table": (c_int, [c_void_p, c_void_p]),
     "hades252_witness_wires": (c_int, []),
     "hades252_warm_up": (c_int, [c_size_t]),
     "hades252_perm_witness_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -122,6 +122,25 @@ int hades252_perm_witness_dev(const void *d_states, void *d_wires, size_t n_perm
     return HADES252_OK;
 }
 
+int hades252_perm_trace_scaled_dev(const void *d_states, void *d_trace, size_t n_perms, void *stream) {
+    if (n_perms == 0) return HADES252_OK;
+    if (d_states == nullptr || d_trace == nullptr || misaligned(d_states) || misaligned(d_trace)) return HADES252_ERR_INVALID_ARG;
+    if (n_perms > kMaxLaunchRecords) return HADES252_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k_perm_trace_scaled, dim3(blocks_for(n_perms)), dim3(kBlock), lds_for(5), (hipStream_t)stream,
+                       (const uint8_t *)d_states, (uint8_t *)d_trace, n_perms);
+    HIP_TRY(hipGetLastError());
+    return HADES252_OK;
+}
+
+int hades252_perm_trace_scale_table(uint64_t *mul, uint64_t *add) {
+    static const uint64_t kMul[67][4] = HADES_TRACE_SCALED_MUL;
+    static const uint64_t kAdd[67][5][4] = HADES_TRACE_SCALED_ADD;
+    if (mul == nullptr || add == nullptr) return HADES252_ERR_INVALID_ARG;
+    memcpy(mul, kMul, sizeof(kMul));
+    memcpy(add, kAdd, sizeof(kAdd));
+    return HADES252_OK;
+}
+
 int hades252_perm_trace_dev(const void *d_states, void *d_trace, size_t n_perms, void *stream) {
     return hades252_perm_trace_dev_ex(d_states, d_trace, n_perms, stream, HADES252_KERNEL_DEFAULT);
 }

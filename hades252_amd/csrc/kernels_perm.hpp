@@ -295,6 +295,34 @@ __global__ void __launch_bounds__(kBlock, 3) k_perm_witness(const uint8_t *__res
     }
 }
 
+// slab_flush (staging.hpp) for a kernel that flushes EVERY ROUND: the slab is private to the wave, so what orders the
+// per-lane ds_write of slab_put against the transposed ds_read here is the wave's own program order (the LDS unit serves a
+// wave's requests in order) -- not a block barrier.  Two s_barrier per round would march the four waves of a block in
+// lockstep: all of them store together, none of them issues arithmetic meanwhile (measured on the scaled trace, 2^20 states:
+// see profiles/r6/).  The wavefront-scope fences only keep the compiler from moving LDS accesses across the hand-over.
+template <int NW>
+__device__ __forceinline__ void slab_flush_wave(uint8_t *base, size_t rec0, size_t n_recs, uint8_t *slab) {
+    constexpr int kLdsRecBytes = lds_rec_bytes(NW);
+    const int lane = threadIdx.x & (kWave - 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const size_t rec_bytes = (size_t)NW * 32;
+    const size_t total_chunks = n_recs * (size_t)(2 * NW);
+    uint4 *g = reinterpret_cast<uint4 *>(base + rec0 * rec_bytes);
+    const size_t chunk0 = rec0 * (size_t)(2 * NW);
+#pragma unroll
+    for (int k = 0; k < 2 * NW; k++) {
+        int c = k * kWave + lane;
+        int rec = c / (2 * NW), part = c - rec * (2 * NW);
+        uint4 v = *reinterpret_cast<const uint4 *>(slab + rec * kLdsRecBytes + part * 16);
+        if (chunk0 + c < total_chunks) g[c] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Per-round trace, shipped form: the state after every round (reference src/strategies.rs:140-157 observed round by round;
 // what the gadget's rows are before the next round key), round-major: trace[r] is a whole AoS batch.  The rounds of
 // k_perm_witness -- every value held as x Rp, the linear layer as one constant linear map per word + the small-integer
@@ -361,11 +389,76 @@ __global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__
         small_mds(y);
 #pragma unroll
         for (int w = 0; w < 5; w++) slab_put<5>(slab, w, finalize32(y[w]));
-        slab_flush<5>(trace + (size_t)r * n * 160, rec0, n, slab);
+        slab_flush_wave<5>(trace + (size_t)r * n * 160, rec0, n, slab);
 #pragma unroll
         for (int w = 0; w < 5; w++)
 #pragma unroll
             for (int k = 0; k < kNL; k++) limb_fence(y[w].l[k]);
+    }
+}
+
+// x mod p, fully reduced, for the values the throughput kernel's linear layer leaves: NORMALISED limbs (0..7 in [0, 2^29),
+// the signed top limb carries the sign) and x in (-p - 2^250, 2^250].  Almost all of that window is [-p, 0) -- the layer's
+// one-limb Montgomery step subtracts m p with m uniform in [0, 2^29) from a sum of magnitude below 2^-8 p 2^29 -- where the
+// answer is x + p and nothing else.  So: pack the limbs straight into the 256-bit two's-complement image of x (no carry
+// pass: they are normalised), add p once, and take the two rare sides -- x >= 0: x itself; x < -p: one more p -- on a
+// wave-uniform branch that a wave skips unless one of its lanes needs it (a few per thousand words).  36 + 4 instructions on
+// the common path against the 87 of `finalize` (carry pass with 2 p, packing, two conditional subtractions).
+// tests/test_fast_model.py::finalize_window_model replays it on the window's edges.
+__device__ __forceinline__ Fr finalize_window(const F29 &x) {
+    const Fr t = from_f29(x);                           // x mod 2^256
+    Fr u;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint64_t s = (uint64_t)t.l[i] + FR_P[i] + c;
+        u.l[i] = (uint32_t)s;
+        c = s >> 32;
+    }
+    const bool pos = (int32_t)t.l[7] >= 0;             // x >= 0 (below 2^250 < p): canonical as it stands
+    const bool low = (int32_t)u.l[7] < 0;              // x + p < 0: one more p
+    if (__any(pos || low)) {
+        Fr v;
+        c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint64_t s = (uint64_t)u.l[i] + FR_P[i] + c;
+            v.l[i] = (uint32_t)s;
+            c = s >> 32;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) u.l[i] = pos ? t.l[i] : (low ? v.l[i] : u.l[i]);
+    }
+    return u;
+}
+
+// Per-round trace, SCALED form (opt-in: hades252_perm_trace_scaled_dev).  The true-form kernel above pays 485 multiply-adds
+// per round to keep every word at scale Rp so that a word can leave through finalize32; here the rounds are the throughput
+// kernel's own (fast_round: the state carries the running scale s_r and, in the partial rounds, lacks the constants still
+// deferred), and a word leaves through `finalize_window` ALONE -- pack, add p, a rarely taken fix-up: no product.
+// What is stored is a fully reduced field element all the same: scaled[r][w] = s_after(r) (true[r][w] - d_r[w]) mod p, and
+// the consumer recovers true[r][w] = scaled[r][w] * MUL[r] + ADD[r][w] (BlsScalar operations, 67 multipliers + 67 x 5
+// addends from hades252_perm_trace_scale_table) lazily -- fused into whatever reads the trace next -- or never, where a
+// relation is homogeneous.  The window (-p - 2^250, 2^250] holds for every word the linear layer produces
+// (tests/test_fast_model.py::test_scaled_trace_model_matches_spec_oracle asserts it round by round).
+__global__ void __launch_bounds__(kBlock, 4) k_perm_trace_scaled(const uint8_t *__restrict__ states,
+                                                                 uint8_t *__restrict__ trace, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t *slab = wave_slab<5>(lds);
+    const size_t rec0 = (size_t)blockIdx.x * kBlock + (threadIdx.x / kWave) * kWave;
+    F29 st[5];
+    {
+        Fr in[5];
+        wave_load_records<5>(states, rec0, n, slab, in);
+#pragma unroll
+        for (int w = 0; w < 5; w++) st[w] = to_f29(in[w]);
+    }
+#pragma unroll 1
+    for (int r = 0; r < 67; r++) {
+        fast_round(d_fast.round[r], d_fast.lin[r], r < 4 || r >= 63, st);
+#pragma unroll
+        for (int w = 0; w < 5; w++) slab_put<5>(slab, w, finalize_window(st[w]));
+        slab_flush_wave<5>(trace + (size_t)r * n * 160, rec0, n, slab);
     }
 }
 

@@ -384,6 +384,26 @@ def perm_trace(states_t, kernel: int = _lib.KERNEL_DEFAULT, out=None):
     return trace
 
 
+def perm_trace_scaled(states_t, out=None):
+    """The per-round trace in SCALED form (include/hades252.h: hades252_perm_trace_scaled_dev): same shape as
+    ``perm_trace``; ``true[r][w] = scaled[r][w] * mul[r] + add[r][w]`` with the tables of ``trace_scale_table()``."""
+    import torch
+    ptr, n, dev = _dev_buffer(states_t, STATE_BYTES, "perm_trace_scaled")
+    trace = torch.empty((Strategy.rounds(), n, WIDTH, 4), dtype=torch.int64, device=dev) if out is None else out
+    with torch.cuda.device(dev):
+        check(_lib.lib().hades252_perm_trace_scaled_dev(ptr, trace.data_ptr(), n, _stream_ptr(dev)), "perm_trace_scaled")
+    return trace
+
+
+def trace_scale_table():
+    """(mul [67, 4], add [67, 5, 4]) uint64 numpy arrays: in-memory BlsScalar limbs (host tables, no device call)."""
+    mul = np.zeros((Strategy.rounds(), 4), dtype=np.uint64)
+    add = np.zeros((Strategy.rounds(), WIDTH, 4), dtype=np.uint64)
+    check(_lib.lib().hades252_perm_trace_scale_table(mul.ctypes.data_as(ctypes.c_void_p), add.ctypes.data_as(ctypes.c_void_p)),
+          "trace_scale_table")
+    return mul, add
+
+
 def witness_wires() -> int:
     """Gate outputs per permutation (972): the first dimension of what ``perm_witness`` returns."""
     return int(_lib.lib().hades252_witness_wires())

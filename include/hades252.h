@@ -228,6 +228,16 @@ int hades252_perm_trace_dev(const void *d_states, void *d_trace, size_t n_perms,
  * ~35 M/s); identical bits. */
 int hades252_perm_trace_dev_ex(const void *d_states, void *d_trace, size_t n_perms, void *stream, int kernel);
 
+/* The same trace in SCALED form (opt-in, ~2x the rate): trace[r] holds, fully reduced, the state the throughput kernel
+ * carries after round r -- the true state times the running scale of the schedule, without the constants the partial rounds
+ * defer -- so a word leaves the kernel without a multiplication.  The consumer recovers
+ *     true[r][w] = scaled[r][w] * mul[r] + add[r][w]        (BlsScalar multiplication and addition, in-memory values)
+ * with the 67 multipliers and 67 x 5 addends of hades252_perm_trace_scale_table (mul: 67 x 4 u64, add: 67 x 5 x 4 u64, host
+ * memory, Montgomery limbs like every BlsScalar here; add[r] is zero in the full rounds) -- lazily, fused into whatever
+ * reads the trace next.  Same layout and size as hades252_perm_trace_dev; d_states is not modified. */
+int hades252_perm_trace_scaled_dev(const void *d_states, void *d_trace, size_t n_perms, void *stream);
+int hades252_perm_trace_scale_table(uint64_t *mul, uint64_t *add);
+
 /* Full gadget witness: every gate output GadgetStrategy assigns for a permutation (src/strategies/gadget.rs:41-133),
  * hades252_witness_wires() = 972 values per state in gate order:
  *   round 0: 5 x (w + c);  every round: per S-boxed word v^2, v^4, v^5 (5 words in a full round, the last word in a

@@ -45,6 +45,15 @@ def test_bench_single_and_two_ranks_agree():
     gw = one["secondary"]["gadget_witness"]                           # f4: 972 wires per state, priced against HBM
     assert gw["last_rows_equal_perm"] is True and gw["roofline"]["bound"] == "hbm" and 0.15 < gw["roofline"]["frac"] < 1.0
     assert gw["trace"]["last_round_equals_perm"] is True and 0.1 < gw["trace"]["roofline"]["frac"] < 1.0
+    ts = gw["trace_scaled"]                                            # the opt-in scaled form: faster, same information
+    assert ts["last_round_times_mul_equals_perm"] is True and ts["roofline"]["frac"] > gw["trace"]["roofline"]["frac"]
+    # BASELINE configs[4] at N = 1 (the first point of the strong-scaling curve): all 2^30 outputs against the oracle's digest
+    c5 = one["secondary"]["config5_2p30"]
+    assert c5["scaling"] == "strong" and c5["total_perms"] == 1 << 30 and c5["digest_matches_oracle_at_full_size"] is True
+    assert c5["shard_digests_match_oracle"] is True and c5["parity_vs_cpu_sample"] is True and c5["value"] > 1e8
+    cb = one["cpu_baseline"]                                           # both builds of the same source, side by side
+    assert cb["builds"]["portable"]["flags"].endswith("x86-64-v3") and cb["flags"] in (cb["builds"]["portable"]["flags"], "gcc -O3 -march=native")
+    assert cb["value"] == max(b["value"] for b in cb["builds"].values() if "value" in b)
     assert 0 < hp["pageable_ms"] < 3 * hp["ms"]                       # ordinary memory on fresh pages: staging threads
     assert one["config"]["kernel"] == "k_perm_fast" and "valu_issue" in one and "frac_of_measured" not in one["valu_issue"]
     assert one["n_gpus"] == 1 and one["parity_vs_cpu_sample"] is True
@@ -55,7 +64,8 @@ def test_bench_single_and_two_ranks_agree():
     assert cx["rows"][0]["n"] == 1 and cx["gpu_beats_one_core_from_n"] is not None and cx["gpu_beats_all_cores_from_n"] is not None
     assert cx["gpu_beats_one_core_from_n"] <= cx["gpu_beats_all_cores_from_n"] <= 4096
     # counter-backed traffic of the secondary kernels comes from the keyed record or is null -- never a literal
-    for rl in (mk["roofline"], wf["to_bytes"]["roofline"], wf["from_bytes"]["roofline"], gw["roofline"], gw["trace"]["roofline"]):
+    for rl in (mk["roofline"], wf["to_bytes"]["roofline"], wf["from_bytes"]["roofline"], gw["roofline"], gw["trace"]["roofline"],
+               ts["roofline"]):
         assert "traffic" in rl and (rl["traffic"] is None or 0.9 < rl["traffic_over_algorithmic"] < 1.5)
     assert one["cpu_baseline"]["kind"] == "port" and one["cpu_baseline"]["cores"] >= 1
     assert one["vs_baseline"] is None and one["scaling"] == "weak" and one["config"]["workload"]

@@ -192,3 +192,72 @@ def test_preimage_fails_like_reference(torch_cuda, H):
     wn[300, 17, 0] ^= 1                                                  # wire 300 of state 17: one bit
     bad = gate_violations(torch, H, stn, wn)
     assert 300 in bad and len(bad) <= 12, bad                           # its own gate + the few gates that consume it
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The per-round trace in SCALED form (round 6; hades252_perm_trace_scaled_dev + hades252_perm_trace_scale_table): what the
+# throughput kernel holds after every round, fully reduced; true[r][w] = scaled[r][w] * mul[r] + add[r][w].
+# ---------------------------------------------------------------------------------------------------------------
+def _unscale(torch, H, scaled, mul, add):
+    """The consumer's side, on the device with the library's own BlsScalar operations (hades252_fr_op_dev)."""
+    rounds, n = scaled.shape[0], scaled.shape[1]
+    out = torch.empty_like(scaled)
+    for r in range(rounds):
+        m = to_dev(torch, np.tile(mul[r], n * 5)).view(-1, 4)
+        a = to_dev(torch, np.tile(add[r].reshape(-1), n)).view(-1, 4)
+        prod = H.fr_op(H.FR_MUL, scaled[r].reshape(-1, 4).contiguous(), m)
+        out[r] = H.fr_op(H.FR_ADD, prod, a).view(n, 5, 4)
+    return out
+
+
+def test_scaled_trace_times_table_is_the_oracle_trace(torch_cuda, H, oracle):
+    torch = torch_cuda
+    mul, add = H.trace_scale_table()
+    rng = random.Random(606)
+    edge = [0, 1, P - 1, R, P - R, (1 << 255) % P, (1 << 254) - 1]
+    cases = [[1] * 5, [0] * 5, [P - 1] * 5, [17] * 5, [5000] * 5] + [[rng.choice(edge) for _ in range(5)] for _ in range(11)]
+    cases += [[rng.randrange(P) for _ in range(5)] for _ in range(48)]
+    st = scalars_dev(torch, [S.to_mont(v) for c in cases for v in c]).view(-1, 5, 4)
+    keep = st.clone()
+    scaled = H.perm_trace_scaled(st)
+    assert torch.equal(st, keep)                                        # the input is left untouched
+    assert tuple(scaled.shape) == (67, len(cases), 5, 4)
+    got = _unscale(torch, H, scaled, mul, add)
+    for i, c in enumerate(cases):                                       # every round, every word, against the ORACLE's trace
+        _, tr = oracle.perm_trace(np.array([l for v in c for l in limbs_of(S.to_mont(v))], dtype=np.uint64))
+        assert (to_host(got[:, i]).reshape(67, 5, 4) == tr).all(), i
+    # every stored value is a fully reduced field element
+    host = to_host(scaled).reshape(-1, 4)
+    assert all(int_of(row) < P for row in host[:: max(1, len(host) // 500)])
+    # scale 1 and no deferred constants after the last round?  No: the last round still carries the schedule's final scale
+    assert not torch.equal(scaled[66], got[66]) and (add[66] == 0).all() and (add[0] == 0).all() and add[30].any()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 257, 4097])
+def test_scaled_trace_ragged_sizes_equal_true_trace(torch_cuda, H, n):
+    """Any n (ragged last wave / block), guard rows around the output, against the shipped true-form trace kernel."""
+    torch = torch_cuda
+    mul, add = H.trace_scale_table()
+    st = H.gen_b(5 * n, "cuda", first_elem=5 * 1234).view(n, 5, 4)
+    guard = 0x5A5A5A5A5A5A5A5A
+    buf = torch.full((67 * n * 20 + 40,), guard, dtype=torch.int64, device="cuda")
+    out = buf[20:20 + 67 * n * 20].view(67, n, 5, 4)
+    H.perm_trace_scaled(st, out=out)
+    assert (buf[:20] == guard).all() and (buf[-20:] == guard).all()
+    assert torch.equal(_unscale(torch, H, out, mul, add), H.perm_trace(st))
+
+
+def test_scaled_trace_at_scale_last_round_is_perm(torch_cuda, H):
+    """2^18 states: the un-scaled last round equals the permutation itself; a strided sample of rounds equals the true trace."""
+    torch = torch_cuda
+    n = 1 << 18
+    mul, add = H.trace_scale_table()
+    st = H.gen_b(5 * n, "cuda").view(n, 5, 4)
+    scaled = H.perm_trace_scaled(st)
+    true = H.perm_trace(st)
+    for r in (0, 3, 4, 30, 62, 63, 66):
+        got = _unscale(torch, H, scaled[r:r + 1], mul[r:r + 1], add[r:r + 1])
+        assert torch.equal(got[0], true[r]), r
+    out = st.clone().view(-1)
+    H.ScalarStrategy().perm(out)
+    assert torch.equal(_unscale(torch, H, scaled[66:67], mul[66:67], add[66:67])[0].reshape(-1), out)

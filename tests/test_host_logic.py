@@ -115,3 +115,16 @@ def test_staging_threads_never_outnumber_the_usable_cpus():
             for workers, t in zip((1, 2, 4, 8, 64, 1, 1), per_workers):         # (0 and negative mean one caller)
                 assert t == max(1, min(configured, cpus // (2 * workers))), (cpus, env_threads, workers, t)
                 assert t == 1 or workers * 2 * t <= cpus
+
+
+def test_trace_scale_table_of_the_library_is_the_derived_one():
+    """hades252_perm_trace_scale_table copies host tables (no HIP call): they are D.trace_scaled_tables(), i.e.
+    mul[r] = R^2 / s_after(r), add[r][w] = (deferred constant) * R -- the limb model checks the algebra against the oracle
+    (tests/test_fast_model.py::test_scaled_trace_model_matches_spec_oracle)."""
+    from oracle_lib import int_of
+    mul, add = H.trace_scale_table()
+    want_mul, want_add = D.trace_scaled_tables()
+    assert mul.shape == (67, 4) and add.shape == (67, 5, 4)
+    assert [int_of(m) for m in mul] == want_mul
+    assert [[int_of(a) for a in row] for row in add] == want_add
+    assert all(v < D.P for v in want_mul) and len(set(want_mul)) == 67

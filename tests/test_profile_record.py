@@ -52,7 +52,7 @@ def test_measured_commit_really_holds_the_measured_kernel():
     #  replayed by bench.py: `traffic` null.  Only a record that CLAIMS today's sources is held to its commit.)
     if sec and sec["device_source_hash"] == build.device_source_hash():
         assert stamp_profile.device_source_hash_at(sec["measured_at_commit"]) == sec["device_source_hash"]
-        for key in ("wire_to_bytes", "wire_from_bytes", "witness", "trace", "merkle_2p24_tree"):
+        for key in ("wire_to_bytes", "wire_from_bytes", "witness", "trace", "trace_scaled", "merkle_2p24_tree"):
             assert sec[key]["hbm_bytes"] > 0
 
 

@@ -28,5 +28,6 @@ out["wire_format"] = {"to_bytes_ms": w["to_bytes"]["ms"], "from_bytes_ms": w["fr
                       "from_bytes_launches": w["launches"]["from_bytes"]}
 g = bench.gadget_witness_record(H, torch, dev)
 out["gadget_witness"] = {"witness_ms": g["ms"], "trace_ms": g["trace"]["ms"], "witness_launches": g["launches"],
-                         "trace_launches": g["trace"]["launches"]}
+                         "trace_launches": g["trace"]["launches"], "trace_scaled_ms": g["trace_scaled"]["ms"],
+                         "trace_scaled_launches": g["trace_scaled"]["launches"]}
 print(json.dumps(out), flush=True)

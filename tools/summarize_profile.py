@@ -65,6 +65,7 @@ def secondary_kernels(build):
     trees = counts["merkle_2p24"]["trees_built"]
     groups = {"wire_to_bytes": lambda k: "k_wire<0>" in k, "wire_from_bytes": lambda k: "k_wire<1>" in k,
               "witness": lambda k: "k_perm_witness" in k, "trace": lambda k: "k_perm_trace_fast" in k,
+              "trace_scaled": lambda k: "k_perm_trace_scaled" in k,
               "merkle_2p24_tree": lambda k: "merkle" in k}
     acc = {g: {"FETCH_SIZE": [], "WRITE_SIZE": []} for g in groups}
     for d in ("pmc_sec_fetch", "pmc_sec_write"):
