@@ -223,3 +223,23 @@ def test_small_batch_streaming_absorb(torch_cuda, H, oracle):
             blocks[:n] = to_dev(torch, msgs).view(n, t, 4, 4)
             big.absorb(blocks)
             assert torch.equal(big.states[:n], st.states)
+
+
+def test_sponge_golden_vectors_on_the_device(torch_cuda, H, oracle, kat):
+    """The committed sponge vectors (tests/golden/kat.json `sponge`, the ones rust/tests/kat_scalar.rs hands to the real
+    crate's `perm`) through the HIP path: one ragged batch per (capacity, padding rule)."""
+    torch = torch_cuda
+    vecs = kat["sponge"]["vectors"]
+    groups = {}
+    for v in vecs:
+        groups.setdefault((v["capacity"], v["pad_mode"]), []).append(v)
+    assert len(groups) == 4
+    for (cap_hex, pad), vs in groups.items():
+        pool = np.concatenate([oracle.gen_b(v["first_elem"], v["len"]) for v in vs] + [np.zeros(4, dtype=np.uint64)])
+        lengths = [v["len"] for v in vs]
+        offsets = [sum(lengths[:i]) for i in range(len(vs))]
+        got = H.sponge_hash_var(to_dev(torch, pool), to_dev(torch, np.array(offsets, dtype=np.uint64)),
+                                to_dev(torch, np.array(lengths, dtype=np.uint64)), S.to_mont(int(cap_hex, 16)), pad)
+        host = to_host(got).reshape(-1, 4)
+        for i, v in enumerate(vs):
+            assert int_of(host[i]) == int(v["digest_mont"], 16), v

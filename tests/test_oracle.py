@@ -275,3 +275,15 @@ def test_headline_block_digests_are_consistent_with_the_config5_run(oracle, kat)
     pr = rec["probe"]
     out = oracle.perm_batch(oracle.gen_b(5 * pr["first_state"], 5 * pr["n"]))
     assert ["%016x" % x for x in oracle_lib.digest_ref(out, 20 * pr["first_state"])] == pr["digest"]
+
+
+def test_sponge_golden_vectors_through_the_c_oracle(oracle, kat):
+    """tests/golden/kat.json `sponge` (written from the big-integer spec; embedded in rust/tests/kat_scalar.rs for the real
+    crate's `perm` to confirm): the C oracle's variable-length sponge on the same generator-B messages."""
+    vecs = kat["sponge"]["vectors"]
+    assert len(vecs) == 32
+    for v in vecs:
+        msg = oracle.gen_b(v["first_elem"], v["len"])
+        cap = S.to_mont(int(v["capacity"], 16))
+        got = oracle.sponge_var(msg if v["len"] else np.zeros(4, dtype=np.uint64), [0], [v["len"]], cap, v["pad_mode"])
+        assert int_of(got) == int(v["digest_mont"], 16), v

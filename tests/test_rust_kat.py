@@ -126,6 +126,34 @@ def test_generator_b_text_is_the_spec():
     assert S.GEN_SEED == 0x4861646573323532
 
 
+def test_caller_shape_vectors_are_the_oracles():
+    """Merkle roots and sponge digests embedded for `kat_merkle4_roots_over_perm` / `kat_sponge_over_perm`: parsed back out of
+    the Rust text and re-derived from oracle/hades_spec.py; the Rust restatements of node / sponge carry the spec's steps."""
+    def leaf(e):
+        l = S.gen_b_element(e)
+        return S.from_mont(sum(l[k] << (64 * k) for k in range(4)))
+    roots = re.findall(r"^    \((\d+), %s\),$" % LIMBS, TEXT, flags=re.M)
+    assert [int(r[0]) for r in roots] == [4, 16, 64, 256]
+    for r in roots:
+        n = int(r[0])
+        assert val(r[1:5]) == S.to_mont(S.merkle4_root([leaf(e) for e in range(n)], 15, 1)) == int(
+            KAT["merkle4_root_mont"]["leaves_gen_b"][str(n)], 16)
+    vecs = re.findall(r"^    \((\d+), (\d+), %s, (true|false), %s\),$" % (LIMBS, LIMBS), TEXT, flags=re.M)
+    assert len(vecs) == len(KAT["sponge"]["vectors"]) == 32
+    seen = set()
+    for v, k in zip(vecs, KAT["sponge"]["vectors"]):
+        first, length, cap, pad = int(v[0]), int(v[1]), val(v[2:6]), v[6] == "true"
+        assert (first, length, cap, 1 if pad else 0) == (k["first_elem"], k["len"], int(k["capacity"], 16), k["pad_mode"])
+        msg = [leaf(first + e) for e in range(length)]
+        assert val(v[7:11]) == S.to_mont(S.sponge_hash(msg, cap, 1 if pad else 0)) == int(k["digest_mont"], 16)
+        seen.add((length, cap, pad))
+    assert len(seen) == 32 and {l for l, _, _ in seen} == {0, 1, 3, 4, 5, 8, 9, 17}
+    for stmt in ("let mut state = [tag, c[0], c[1], c[2], c[3]];", "state[out_idx]", "state[1 + k] += block[k];",
+                 "padded.push(BlsScalar::from(1u64));", "while padded.len() % 4 != 0", "state[1]\n}",
+                 "BlsScalar::from(15u64), 1)"):
+        assert stmt in TEXT, stmt
+
+
 def strip_strings_and_comments(text):
     text = re.sub(r"//[^\n]*", "", text)
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -168,5 +196,6 @@ def test_only_names_the_reference_uses_or_exports():
     assert "#![allow(deprecated)]" in TEXT                          # src/lib.rs:10 marks the whole crate deprecated
     assert 'include_bytes!("../assets/ark.bin")' in TEXT            # tests/ -> crate root, like src/round_constants.rs:30
     for t in ("layout_and_montgomery_form", "loader_reading_of_the_constant_blobs", "kat_single_states",
-              "kat_round_intermediates", "sha256_self_test", "kat_batch_generator_a", "kat_batch_generator_b"):
+              "kat_round_intermediates", "sha256_self_test", "kat_batch_generator_a", "kat_batch_generator_b",
+              "kat_merkle4_roots_over_perm", "kat_sponge_over_perm"):
         assert re.search(r"#\[test\]\s*fn %s\(\)" % t, TEXT), t
