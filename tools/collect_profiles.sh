@@ -27,6 +27,10 @@ c $G/host_callers_$TAG.txt $P/host_callers.txt
 c $G/host_path_$TAG.txt $P/host_path_native.txt
 c $G/host_path_torch_probe_$TAG.txt $P/host_path_torch_probe.txt
 c $G/bench_rehearsal_2ranks.json $P/bench_rehearsal_2ranks_one_device.json
+c $G/bench_rehearsal_8ranks.json $P/bench_rehearsal_8ranks_one_device.json
+# round 6: BASELINE configs[4] as a strong-scaling measurement (tools/gpu_session_r6a.sh)
+c $G/r6a/bench_strong_2p30_N1.json $P/bench_strong_2p30_N1.json
+c $G/r6a/bench_strong_rehearsal_2ranks.json $P/bench_strong_rehearsal_2ranks_one_device.json
 for f in lanes_proto pcie_probe residency ubench3 dfma_proto wire_proto copy_proto pin_probe; do c $G/${f}_$TAG.txt $P/$f.txt; done
 tail -6 $G/pytest_gpu_$TAG.txt > $P/pytest_gpu_summary.txt
 ls -la $P
