@@ -184,7 +184,8 @@ int hades252_apply_partial_round_dev(void *d_states, size_t n_states, int round,
 }
 
 int hades252_fr_op_dev(int op, int impl, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream) {
-    if (op < FR_ADD || op > FR_FROM_RAW || (impl != 0 && impl != 1)) return HADES252_ERR_INVALID_ARG;
+    if (op < FR_ADD || op > FR_REDUCE_SIGNED || (impl != 0 && impl != 1)) return HADES252_ERR_INVALID_ARG;
+    if (op == FR_REDUCE_SIGNED && impl != 1) return HADES252_ERR_INVALID_ARG;          // a radix-2^29 routine
     if (n == 0) return HADES252_OK;
     const bool binary = (op == FR_ADD || op == FR_MUL);
     if (d_a == nullptr || d_out == nullptr || (binary && d_b == nullptr) || n > kMaxLaunchRecords || misaligned(d_a) ||

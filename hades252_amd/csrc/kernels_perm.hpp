@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_perm_trace_scaled(const uint8_t *
 // IMPL 1: the radix-2^29 signed-limb arithmetic of the shipped kernel (to_f29, mont_fips, finalize).
 // These exist so that tests can drive BOTH device arithmetics through the computations that produced
 // the reference's constant blobs (tests/test_gpu_blob_kat.py), and as a13's batched surface.
-enum FrOp { FR_ADD = 0, FR_MUL = 1, FR_SQUARE = 2, FR_FROM_RAW = 3 };
+enum FrOp { FR_ADD = 0, FR_MUL = 1, FR_SQUARE = 2, FR_FROM_RAW = 3, FR_REDUCE_SIGNED = 4 };
 template <int IMPL>
 __global__ void __launch_bounds__(kBlock) k_fr_op(const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, int op) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -489,7 +489,12 @@ __global__ void __launch_bounds__(kBlock) k_fr_op(const uint8_t *a, const uint8_
         r[0] = (op == FR_ADD) ? fr_add(x[0], y[0]) : fr_mul(x[0], y[0]);
     } else {
         F29 xa = to_f29(x[0]), yb = to_f29(y[0]);
-        if (op == FR_ADD) {
+        if (op == FR_REDUCE_SIGNED) {
+            // a = two's-complement image of a signed x in (-p - 2^250, 2^250]: the exit of the scaled trace kernel
+            // (finalize_window) on values a test chooses -- both of its rare sides included
+            xa.l[kNL - 1] = (int32_t)x[0].l[7] >> 8;               // bits 232 .. 255, sign-extended
+            r[0] = finalize_window(xa);
+        } else if (op == FR_ADD) {
             add_lazy(xa, yb.l);                                    // limbs < 2^30
             r[0] = finalize(mont_mul_const(xa, d_rp_mod_p));       // (a + b) * Rp / Rp
         } else {

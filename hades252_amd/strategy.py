@@ -421,7 +421,7 @@ def perm_witness(states_t, out=None):
     return wires
 
 
-FR_ADD, FR_MUL, FR_SQUARE, FR_FROM_RAW = 0, 1, 2, 3
+FR_ADD, FR_MUL, FR_SQUARE, FR_FROM_RAW, FR_REDUCE_SIGNED = 0, 1, 2, 3, 4
 FR_IMPL_SATURATED32, FR_IMPL_RADIX29 = 0, 1
 
 

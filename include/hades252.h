@@ -270,7 +270,9 @@ int hades252_apply_partial_round_at_dev(void *d_states, size_t n_states, int cur
 /* ---- BlsScalar arithmetic, batched (external crate dusk-bls12_381; call sites src/strategies/scalar.rs:28,
  * :33, :44, src/round_constants.rs:41) ------------------------------------------------------------------
  * out[i] = a[i] op b[i] on Montgomery limbs (32 B each, fully reduced in and out; out may alias a or b).
- * op: 0 add, 1 mul, 2 square (b ignored), 3 from_raw (a = canonical limbs, b ignored).
+ * op: 0 add, 1 mul, 2 square (b ignored), 3 from_raw (a = canonical limbs, b ignored), 4 reduce_signed (impl 1 only; a =
+ *     the 256-bit two's-complement image of a signed integer x in (-p - 2^250, 2^250], b ignored; out = x mod p as plain
+ *     limbs: the exit routine of the scaled per-round trace, exposed so that its rare branches can be driven directly).
  * impl: 0 = saturated 8 x u32 arithmetic of the literal kernels, 1 = radix-2^29 signed-limb arithmetic
  * of the shipped kernel.  Both give identical bits; tests regenerate the reference's constant blobs
  * through each of them. */
@@ -278,6 +280,7 @@ int hades252_apply_partial_round_at_dev(void *d_states, size_t n_states, int cur
 #define HADES252_FR_MUL 1
 #define HADES252_FR_SQUARE 2
 #define HADES252_FR_FROM_RAW 3
+#define HADES252_FR_REDUCE_SIGNED 4
 int hades252_fr_op_dev(int op, int impl, const void *d_a, const void *d_b, void *d_out, size_t n, void *stream);
 
 /* ---- wire format on device: BlsScalar::from_bytes / to_bytes ------------------------------ */

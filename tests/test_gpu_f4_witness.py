@@ -261,3 +261,23 @@ def test_scaled_trace_at_scale_last_round_is_perm(torch_cuda, H):
     out = st.clone().view(-1)
     H.ScalarStrategy().perm(out)
     assert torch.equal(_unscale(torch, H, scaled[66:67], mul[66:67], add[66:67])[0].reshape(-1), out)
+
+
+def test_finalize_window_both_rare_sides_on_the_device(torch_cuda, H):
+    """The exit routine of the scaled trace (finalize_window: pack, add p, a wave-uniform fix-up branch) driven directly
+    through hades252_fr_op_dev(HADES252_FR_REDUCE_SIGNED): the two sides real states reach a few times per thousand words
+    (x < -p) or practically never (x >= 0), the window's edges, waves where no / one / every lane takes the fix-up."""
+    torch = torch_cuda
+    rng = random.Random(77)
+    edge = [0, 1, -1, -P, -P + 1, -P - 1, 1 << 250, -P - (1 << 250) + 1, -(P >> 1), (1 << 249) + 12345, -P - (1 << 249) - 7,
+            (1 << 250) - 1, -P - 2, 2]
+    common = [-rng.randrange(1, P) for _ in range(64 * 6)]                     # [-p, 0): the fix-up branch is skipped
+    one_lane = list(common[:64]); one_lane[37] = 5                              # one lane of a wave needs it
+    all_lanes = [rng.randrange(0, 1 << 250) for _ in range(32)] + [-P - rng.randrange(1, 1 << 250) for _ in range(32)]
+    xs = common + one_lane + all_lanes + edge + [rng.choice(edge) for _ in range(50)]
+    a = scalars_dev(torch, [x & ((1 << 256) - 1) for x in xs])
+    got = to_host(H.fr_op(H.FR_REDUCE_SIGNED, a)).reshape(-1, 4)
+    for x, row in zip(xs, got):
+        assert int_of(row) == x % P, hex(x)
+    with pytest.raises(Exception):
+        H.fr_op(H.FR_REDUCE_SIGNED, a, impl=H.FR_IMPL_SATURATED32)              # a radix-2^29 routine only
