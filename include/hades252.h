@@ -228,7 +228,7 @@ int hades252_perm_trace_dev(const void *d_states, void *d_trace, size_t n_perms,
  * ~35 M/s); identical bits. */
 int hades252_perm_trace_dev_ex(const void *d_states, void *d_trace, size_t n_perms, void *stream, int kernel);
 
-/* The same trace in SCALED form (opt-in, ~2x the rate): trace[r] holds, fully reduced, the state the throughput kernel
+/* The same trace in SCALED form (opt-in, ~1.5x the rate: 313 against 215 M permutations/s at 2^20 states): trace[r] holds, fully reduced, the state the throughput kernel
  * carries after round r -- the true state times the running scale of the schedule, without the constants the partial rounds
  * defer -- so a word leaves the kernel without a multiplication.  The consumer recovers
  *     true[r][w] = scaled[r][w] * mul[r] + add[r][w]        (BlsScalar multiplication and addition, in-memory values)
