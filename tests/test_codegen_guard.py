@@ -75,13 +75,29 @@ def test_perm_fast_instruction_mix(device_asm):
 
 
 @pytest.mark.parametrize("needle", ["k_perm_fast", "k_sponge", "k_merkle_level_fast", "k_merkle_coop", "k_perm_coop",
-                                    "k_perm_trace_fast", "k_perm_witness", "k_fr_op", "k_perm_lanes", "k_merkle_lanes",
+                                    "k_perm_trace_fast", "k_perm_trace_scaled", "k_perm_witness", "k_fr_op", "k_perm_lanes", "k_merkle_lanes",
                                     "k_merkle_verify", "k_merkle_update", "k_wire", "k_perm_rows", "k_merkle_rows"])
 def test_hot_kernels_have_no_scratch(device_asm, needle):
     _, res = device_asm
     for name in find(res, needle):
         assert res[name]["ScratchSize"] == 0, (name, res[name])
         assert res[name]["VGPRs Spill"] == 0, (name, res[name])      # (SGPR spills go to VGPR lanes, not memory)
+
+
+def test_scaled_trace_kernel_is_the_throughput_round_plus_a_cheap_exit(device_asm):
+    """k_perm_trace_scaled = the round body of k_perm_fast (one per round kind) + five exits per round: its multiply-add count
+    is the throughput kernel's minus the final un-scaling maps (5 x 97), no block barrier inside the round loop (the slab is
+    wave-private: two s_barrier, both in the initial load), four waves per SIMD by registers."""
+    bodies, res = device_asm
+    (name,) = find(bodies, "k_perm_trace_scaled")
+    (fast,) = find(bodies, "k_perm_fast")
+    body = bodies[name]
+    mads = len(re.findall(r"\bv_mad_i64_i32\b", body))
+    fast_mads = len(re.findall(r"\bv_mad_i64_i32\b", bodies[fast]))
+    assert abs(mads - (fast_mads - 5 * 97)) <= 0.02 * fast_mads, (mads, fast_mads)
+    assert len(re.findall(r"\bs_barrier\b", body)) == 2
+    r = res[name]
+    assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0 and r["VGPRs"] <= 128, r
 
 
 def test_wire_kernels_keep_their_occupancy(device_asm):
