@@ -26,7 +26,9 @@ Also in the line:
                 the committed rocprofv3 PMC run (profiles/), or null.
   cpu_baseline  the CPU oracle (oracle/hades_oracle.c, a port: the Rust reference cannot be
                 built in this image) timed on this host (rank 0) on a bounded sample of the same
-                workload; the same sample is used to check the GPU output bit for bit.
+                workload -- two builds of the same source side by side (-march=x86-64-v3, the checker, and
+                -O3 -march=native compiled on this host), `value` = the better; the same sample is used
+                to check the GPU output bit for bit.
   secondary     outside `value`: BASELINE.json configs[3] (arity-4 Merkle tree over 2^24 leaves: tree
                 time, nodes/s, its own roofline with 160 B per node), `single_perm` (ONE permutation: device
                 and host-call latency), `sponge_chain` (one message of 1000 blocks: us per dependent
@@ -36,12 +38,13 @@ Also in the line:
                 PCIe-inclusive) on 2^22 states against this box's measured bidirectional copy ceiling.
   dist          N > 1 evidence: backend, ranks_seen (= the process group's world size), the physical device every rank
                 sat on (PCI address / UUID, gathered) -- two ranks on one device fail the job unless --single-device.
-                With N > 1 every rank also takes part in two more records under `secondary`:
-                `config5_2p30` (BASELINE configs[4] at world size 8: 2^27 states per GPU, 3 timed launches, oracle samples
-                on every rank, the sum of the shard digests against the committed digest of the whole 2^30 batch;
-                `config5_rehearsal` at other world sizes: the same code on --perms-per-gpu states) and
-                `merkle_2p24_sharded` (the 2^24-leaf tree sharded by sub-tree: local sub-roots, ONE all_gather of 32-byte
-                sub-roots -- the path's only exchange step -- and the top levels; root against the oracle's committed root).
+                Every rank (at EVERY N, 1 included) also takes part in `secondary.config5_2p30`: BASELINE configs[4] as a
+                strong-scaling measurement -- 2^30 states in all, 2^30 / N per GPU, 3 timed launches, oracle samples on every
+                rank, every rank's digest of ALL its outputs against the oracle's committed shard digests and their sum against
+                the oracle's digest of the whole batch (`config5_rehearsal` with --single-device: the same code on
+                --perms-per-gpu states per rank) -- and, with N > 1, in `merkle_2p24_sharded` (the 2^24-leaf tree sharded by
+                sub-tree: local sub-roots, ONE all_gather of 32-byte sub-roots -- the path's only exchange step -- and the top
+                levels; root against the oracle's committed root).
   crossover     under `secondary`: the smallest batch for which one hades252_perm_batch call beats the CPU port
                 (one core / all cores) -- the reference's own call shape is ONE permutation per call (README.md:60-61).
 `--workload merkle` times the tree build itself as the step (development; the driver runs the default).
