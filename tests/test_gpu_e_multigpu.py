@@ -175,3 +175,26 @@ def test_bench_refuses_two_ranks_on_one_device(torch_cuda, hades_lib):
     assert [p.returncode for p in procs] == [4, 4], outs
     assert not any(l.startswith("{") for o, _ in outs for l in o.splitlines())
     assert "same physical device" in outs[0][1]
+
+
+def test_bench_strong_scaling_mode_same_batch_at_every_world_size(torch_cuda, hades_lib):
+    """--total-perms T (round 6): T states IN ALL whatever the world size -- one rank, two ranks and three ranks (a world
+    size that does not divide T: shards differ by one state) over the same 2^21 + 1 ... states must leave the same digest
+    after the same number of passes, say `"scaling": "strong"` and report T per step."""
+    common = ["--steps", "2", "--warmup", "1", "--no-secondary", "--no-cpu-baseline"]
+    total = (1 << 21) + 1
+    one, _ = _bench(["--total-perms", str(total)] + common)
+    assert one["scaling"] == "strong" and one["n_gpus"] == 1 and one["config"]["total_perms_per_step"] == total
+    assert one["config"]["perms_per_gpu"] == total and one["parity_vs_cpu_sample"] is True
+    assert abs(one["value"] - total * 2 / (one["ms_per_step"] * 2e-3)) < 1e-6 * one["value"]
+    for world in (2, 3):
+        out, _ = _bench(["--gpus", str(world), "--single-device", "--dist-backend", "gloo", "--total-perms", str(total)] + common)
+        assert out["scaling"] == "strong" and out["n_gpus"] == world and out["config"]["total_perms_per_step"] == total
+        assert out["config"]["perms_per_gpu"] == -(-total // world) and len(out["per_gpu"]["kernel_ms_per_rank"]) == world
+        assert out["digest"] == one["digest"] and out["parity_vs_cpu_sample"] is True
+        assert "IN ALL" in out["config"]["workload"] and "configs[4]" not in out["config"]["workload"]
+    # --total-perms wins over --perms-per-gpu; the weak default is untouched
+    both, _ = _bench(["--total-perms", str(total), "--perms-per-gpu", "4096"] + common)
+    assert both["digest"] == one["digest"] and both["scaling"] == "strong"
+    weak, _ = _bench(["--perms-per-gpu", str(total)] + common)
+    assert weak["scaling"] == "weak" and weak["digest"] == one["digest"]
