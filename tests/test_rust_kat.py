@@ -16,6 +16,8 @@ import os
 import re
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -181,6 +183,18 @@ def test_brackets_balance_in_every_rust_file():
         assert not stack, path
         seen += 1
     assert seen >= 4
+
+
+def test_rust_sources_lex_cleanly():
+    """No Rust parser exists in this image, but pygments ships a Rust LEXER: every shipped .rs file must tokenise without a
+    single error token (unterminated strings / comments, malformed literals, stray characters)."""
+    pygments = pytest.importorskip("pygments")
+    from pygments.lexers import RustLexer
+    from pygments.token import Error
+    for path in rust_sources():
+        toks = list(RustLexer().get_tokens(open(path).read()))
+        bad = [v for t, v in toks if t in Error]
+        assert not bad and len(toks) > 500, (path, bad[:5])
 
 
 def test_only_names_the_reference_uses_or_exports():
