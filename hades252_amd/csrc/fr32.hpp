@@ -21,15 +21,21 @@ struct Fr {
 __device__ static constexpr uint32_t FR_P[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u,
                                                 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
 
+// Multi-word borrow / carry chains are written with clang's subtract- / add-with-carry builtins: they compile to the chain
+// the hardware has (v_sub_co_u32 + 7 v_subb_co_u32).  The portable formulation -- a 64-bit difference per word with the
+// borrow taken from bit 32 -- compiles on gfx950 to 64-bit adds with moves and sign extensions in between (16 v_lshl_add_u64
+// + 16 v_mov + 7 v_ashrrev for eight words: round 6, measured on the kernels that leave through it hundreds of times per
+// state and on the HBM-bound wire kernels, profiles/r6/carry_chain_ab.txt).
+
 // r = a - p if a >= p (a < 2p < 2^256 + p; `top` is the 257th bit)
 __device__ __forceinline__ Fr fr_cond_sub_p(const Fr &a, uint32_t top = 0) {
     Fr d;
-    uint64_t borrow = 0;
+    unsigned borrow = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        uint64_t t = (uint64_t)a.l[i] - FR_P[i] - borrow;
-        d.l[i] = (uint32_t)t;
-        borrow = (t >> 32) & 1u;
+        unsigned bo;
+        d.l[i] = __builtin_subc(a.l[i], FR_P[i], borrow, &bo);
+        borrow = bo;
     }
     // keep d when no borrow happened, or when the borrow is paid by the top bit
     bool use_d = (borrow == 0) || (top != 0);
@@ -41,12 +47,12 @@ __device__ __forceinline__ Fr fr_cond_sub_p(const Fr &a, uint32_t top = 0) {
 
 __device__ __forceinline__ Fr fr_add(const Fr &a, const Fr &b) {
     Fr s;
-    uint64_t c = 0;
+    unsigned c = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        uint64_t t = (uint64_t)a.l[i] + b.l[i] + c;
-        s.l[i] = (uint32_t)t;
-        c = t >> 32;
+        unsigned co;
+        s.l[i] = __builtin_addc(a.l[i], b.l[i], c, &co);
+        c = co;
     }
     return fr_cond_sub_p(s, (uint32_t)c);
 }
@@ -92,11 +98,12 @@ __device__ __forceinline__ Fr fr_sqr(const Fr &a) { return fr_mul(a, a); }
 __device__ __noinline__ Fr fr_mul_call(Fr a, Fr b) { return fr_mul(a, b); }
 
 __device__ __forceinline__ bool fr_is_canonical(const Fr &a) {   // a < p ?
-    uint64_t borrow = 0;
+    unsigned borrow = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        uint64_t t = (uint64_t)a.l[i] - FR_P[i] - borrow;
-        borrow = (t >> 32) & 1u;
+        unsigned bo;
+        (void)__builtin_subc(a.l[i], FR_P[i], borrow, &bo);
+        borrow = bo;
     }
     return borrow != 0;
 }

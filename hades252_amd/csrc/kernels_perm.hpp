@@ -408,12 +408,12 @@ __global__ void __launch_bounds__(kBlock, 3) k_perm_trace_fast(const uint8_t *__
 __device__ __forceinline__ Fr finalize_window(const F29 &x) {
     const Fr t = from_f29(x);                           // x mod 2^256
     Fr u;
-    uint64_t c = 0;
+    unsigned c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint64_t s = (uint64_t)t.l[i] + FR_P[i] + c;
-        u.l[i] = (uint32_t)s;
-        c = s >> 32;
+    for (int i = 0; i < 8; i++) {                       // (add-with-carry builtin: v_add_co_u32 + 7 v_addc_co_u32, see fr32.hpp)
+        unsigned co;
+        u.l[i] = __builtin_addc(t.l[i], FR_P[i], c, &co);
+        c = co;
     }
     const bool pos = (int32_t)t.l[7] >= 0;             // x >= 0 (below 2^250 < p): canonical as it stands
     const bool low = (int32_t)u.l[7] < 0;              // x + p < 0: one more p
@@ -422,9 +422,9 @@ __device__ __forceinline__ Fr finalize_window(const F29 &x) {
         c = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const uint64_t s = (uint64_t)u.l[i] + FR_P[i] + c;
-            v.l[i] = (uint32_t)s;
-            c = s >> 32;
+            unsigned co;
+            v.l[i] = __builtin_addc(u.l[i], FR_P[i], c, &co);
+            c = co;
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) u.l[i] = pos ? t.l[i] : (low ? v.l[i] : u.l[i]);
